@@ -1,0 +1,159 @@
+/*
+ * sip_lqr_amd.h -- C ABI of the MI355X (gfx950) batched regularized-LQR /
+ * Riccati solver.  This is the drop-in boundary for the Newton-KKT linear
+ * solve of joaospinto/sip_optimal_control: every entry point names the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ * The reference solves ONE problem per `LQR` object on the host
+ * (sip_optimal_control/lqr.hpp:66-200).  This library solves `batch`
+ * independent problems of one shape (uniform-dimension chain: the topology
+ * of Topology::set_chain, lqr.cpp:32-40, and of Dimensions::set_uniform,
+ * lqr.cpp:77-88) per call, on the GPU, with device-resident inputs and
+ * outputs.  There is no CPU fallback: every compute entry point fails with
+ * SIP_LQR_ERR_HIP / SIP_LQR_ERR_UNSUPPORTED rather than compute on the host.
+ *
+ * Plain C, plain pointers and sizes, no C++/torch types.  All device
+ * pointers are ordinary HIP device pointers; `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  The caller owns every byte
+ * (as in the reference: lqr.hpp:136-186, "mem_assign"/"num_bytes").
+ *
+ * ------------------------------------------------------------------------
+ * Packed chain layout (device and host-staging buffers; scalar = double for
+ * SIP_LQR_F64, float for SIP_LQR_F32).  All blocks are column-major and
+ * compact (ld = rows), exactly as the reference maps them
+ * (Eigen::Map<MatrixXd>(ptr, rows, cols), e.g. lqr.cpp:654-687).  Problems
+ * are stored one after the other (problem-major); inside a problem, stages
+ * i = 0..T follow each other; node i is the parent of edge i, node i+1 its
+ * child:
+ *
+ *   mats  [batch][ for i in 0..T :  Q_i (n*n) | delta_i (n)          "node"
+ *                    and, if i < T: A_i (n*n) | B_i (n*m) |
+ *                                   M_i (n*m) | R_i (m*m) ]          "edge"
+ *   vecs  [batch][ for i in 0..T :  q_i (n) | c_i (n)   , if i<T: r_i (m) ]
+ *   sol   [batch][ for i in 0..T :  x_i (n) | y_i (n)   , if i<T: u_i (m) ]
+ *   gains [batch][ for i in 0..T-1: K_i (m*n) | k_i (m) ]
+ *   status[batch]  int32, FactorStatus codes below
+ *
+ * mats holds what LQR::factor() reads (LQR::Input::{Q,M,R,A,B,delta},
+ * lqr.hpp:77-85; patched in by helpers.cpp:362-367), vecs what LQR::solve()
+ * additionally reads ({q,r,c}, helpers.cpp:814-816), sol what it writes
+ * (LQR::Output::{x,u,y}, lqr.hpp:91-94), gains the feedback terms
+ * LQR::Workspace::{K,k} (lqr.hpp:112,118).
+ * ------------------------------------------------------------------------
+ */
+#ifndef SIP_LQR_AMD_H
+#define SIP_LQR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-problem factor status: the values of LQR::FactorStatus,
+ * sip_optimal_control/lqr.hpp:68-74. */
+enum {
+  SIP_LQR_SUCCESS = 0,
+  SIP_LQR_INVALID_DELTA = 1,
+  SIP_LQR_F_FACTORIZATION_FAILURE = 2,
+  SIP_LQR_G_FACTORIZATION_FAILURE = 3,
+  SIP_LQR_INVALID_TOPOLOGY = 4
+};
+
+/* API-level return codes (the reference has no error channel besides
+ * FactorStatus; these report misuse of this library). */
+enum {
+  SIP_LQR_OK = 0,
+  SIP_LQR_ERR_INVALID_ARGUMENT = -1,
+  SIP_LQR_ERR_UNSUPPORTED = -2, /* shape/dtype has no HIP kernel */
+  SIP_LQR_ERR_HIP = -3,         /* a HIP runtime call failed   */
+  SIP_LQR_ERR_ALLOC = -4
+};
+
+enum { SIP_LQR_F64 = 0, SIP_LQR_F32 = 1 };
+
+typedef struct sip_lqr_plan sip_lqr_plan;
+
+/* Replaces: LQR::LQR(const Input&, Workspace&) + compile_topology()
+ * (lqr.cpp:635-643) for `batch` problems of horizon T (= num_edges), state
+ * dimension n, control dimension m, on HIP device `device`.  The chain
+ * topology is compiled here once, like the reference caches its traversal
+ * (lqr.cpp:641,646).  Returns SIP_LQR_ERR_UNSUPPORTED when no kernel exists
+ * for (dtype, n, m). */
+int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
+                        int device, sip_lqr_plan **plan);
+void sip_lqr_plan_destroy(sip_lqr_plan *plan);
+
+/* Sizes, in bytes, of the whole-batch buffers.  Replace
+ * LQR::Workspace::num_bytes / LQR::Output::num_bytes (lqr.hpp:104-106,
+ * 146-186); size_t, not int (the reference's int overflows at batch
+ * scale). */
+size_t sip_lqr_mats_bytes(const sip_lqr_plan *plan);
+size_t sip_lqr_vecs_bytes(const sip_lqr_plan *plan);
+size_t sip_lqr_sol_bytes(const sip_lqr_plan *plan);
+size_t sip_lqr_gains_bytes(const sip_lqr_plan *plan);
+size_t sip_lqr_status_bytes(const sip_lqr_plan *plan);
+size_t sip_lqr_workspace_bytes(const sip_lqr_plan *plan);
+/* Per-problem lengths in scalars (packed chain layout above). */
+size_t sip_lqr_mats_len(const sip_lqr_plan *plan);
+size_t sip_lqr_vecs_len(const sip_lqr_plan *plan);
+size_t sip_lqr_gains_len(const sip_lqr_plan *plan);
+
+/* Host-side layout conversion between the reference's per-stage pointer
+ * tables (LQR::Input, lqr.hpp:76-85: double** indexed by node or edge; the
+ * blocks are always double, as in the reference) and the packed chain
+ * layout of problem `p` inside host staging buffers of mats_bytes /
+ * vecs_bytes / sol_bytes.  For SIP_LQR_F32 plans the values are rounded to
+ * float on the way in and widened on the way out. */
+int sip_lqr_pack_problem(const sip_lqr_plan *plan, int64_t p,
+                         double *const *Q, double *const *M, double *const *R,
+                         double *const *q, double *const *r, double *const *A,
+                         double *const *B, double *const *c,
+                         double *const *delta, void *mats_host,
+                         void *vecs_host);
+int sip_lqr_unpack_solution(const sip_lqr_plan *plan, int64_t p,
+                            const void *sol_host, double *const *x,
+                            double *const *u, double *const *y);
+int sip_lqr_unpack_gains(const sip_lqr_plan *plan, int64_t p,
+                         const void *gains_host, double *const *K,
+                         double *const *k);
+
+/* Replaces: the loop body of BM_LQRFactorSolve
+ * (benchmarks/lqr_benchmark.cpp:653-663) = LQR::factor_with_status()
+ * (lqr.cpp:645-731) followed by LQR::solve() (lqr.cpp:735-871), for every
+ * problem of the batch, as one fused launch.  Writes status[p]; sol/gains of
+ * a problem whose status != SUCCESS are unspecified (the reference's solve()
+ * after a failed factor is undefined, lqr.cpp:735).  d_workspace:
+ * sip_lqr_workspace_bytes() of device scratch holding the per-node factor
+ * state the forward rollout needs (the role of LQR::Workspace::{W,V,
+ * F_factor,v,...}, lqr.hpp:110-119). Asynchronous on `stream`. */
+int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
+                         const void *d_vecs, void *d_sol, void *d_gains,
+                         int32_t *d_status, void *d_workspace, void *stream);
+
+/* Replaces: LQR::factor_with_status() alone (lqr.cpp:645-731; called by
+ * CallbackProvider::factor, helpers.cpp:368).  Leaves the factor state in
+ * d_workspace and the K part of d_gains for later sip_lqr_solve() calls. */
+int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
+                   int32_t *d_status, void *d_workspace, void *stream);
+
+/* Replaces: LQR::solve(Output&) alone (lqr.cpp:735-871; called by
+ * CallbackProvider::solve, helpers.cpp:826) against the factor state of the
+ * last sip_lqr_factor() on the same workspace; may be called repeatedly with
+ * new right-hand sides (tests/lqr_test.cpp:431-450).  Fills sol and the k
+ * part of gains. */
+int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats,
+                  const void *d_vecs, void *d_sol, void *d_gains,
+                  void *d_workspace, void *stream);
+
+/* Name of the kernel variant the plan dispatches to (static string). */
+const char *sip_lqr_kernel_name(const sip_lqr_plan *plan);
+
+/* Library version string. */
+const char *sip_lqr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

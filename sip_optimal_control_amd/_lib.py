@@ -1,0 +1,74 @@
+"""ctypes binding of the C ABI declared in include/sip_lqr_amd.h.
+
+Fails loudly (LQRLibraryError) when the HIP library is missing: the product
+has no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libsip_lqr_amd.so"
+
+
+class LQRLibraryError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", _LIB_NAME)
+
+
+# name -> (restype, argtypes); mirrors include/sip_lqr_amd.h one to one.
+_P = ctypes.c_void_p
+_PP = ctypes.POINTER(ctypes.c_void_p)
+_SIGNATURES = {
+    "sip_lqr_plan_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, _PP]),
+    "sip_lqr_plan_destroy": (None, [_P]),
+    "sip_lqr_mats_bytes": (ctypes.c_size_t, [_P]),
+    "sip_lqr_vecs_bytes": (ctypes.c_size_t, [_P]),
+    "sip_lqr_sol_bytes": (ctypes.c_size_t, [_P]),
+    "sip_lqr_gains_bytes": (ctypes.c_size_t, [_P]),
+    "sip_lqr_status_bytes": (ctypes.c_size_t, [_P]),
+    "sip_lqr_workspace_bytes": (ctypes.c_size_t, [_P]),
+    "sip_lqr_mats_len": (ctypes.c_size_t, [_P]),
+    "sip_lqr_vecs_len": (ctypes.c_size_t, [_P]),
+    "sip_lqr_gains_len": (ctypes.c_size_t, [_P]),
+    "sip_lqr_pack_problem": (ctypes.c_int, [_P, ctypes.c_int64] + [_P] * 9 + [_P, _P]),
+    "sip_lqr_unpack_solution": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, _P]),
+    "sip_lqr_unpack_gains": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P]),
+    "sip_lqr_factor_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "sip_lqr_factor": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
+    "sip_lqr_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "sip_lqr_kernel_name": (ctypes.c_char_p, [_P]),
+    "sip_lqr_version": (ctypes.c_char_p, []),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library():
+    """Load lib/libsip_lqr_amd.so and bind every symbol of the header."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise LQRLibraryError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise LQRLibraryError(f"cannot load {path}: {exc}") from exc
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise LQRLibraryError(f"{path} does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

@@ -1,0 +1,108 @@
+"""Batched uniform-chain LQR on the GPU: thin torch/ctypes plumbing over the C ABI.
+
+Mirrors the reference's `LQR` object life cycle (sip_optimal_control/lqr.hpp:
+189-194): construct once per shape (topology compiled once), then
+`factor_solve()` (= factor_with_status() + solve()) as often as needed on
+device-resident packed buffers.  No arithmetic happens in Python.
+"""
+import ctypes
+import enum
+
+import torch
+
+from ._lib import LQRLibraryError, load_library
+from .layout import ChainShape
+
+
+class FactorStatus(enum.IntEnum):
+    """sip_optimal_control/lqr.hpp:68-74."""
+    SUCCESS = 0
+    INVALID_DELTA = 1
+    F_FACTORIZATION_FAILURE = 2
+    G_FACTORIZATION_FAILURE = 3
+    INVALID_TOPOLOGY = 4
+
+
+_DTYPES = {torch.float64: 0, torch.float32: 1}
+
+
+def _check(code, what):
+    if code != 0:
+        names = {-1: "invalid argument", -2: "unsupported shape/dtype (no HIP kernel)",
+                 -3: "HIP runtime error", -4: "allocation failure"}
+        raise LQRLibraryError(f"{what} failed: {names.get(code, code)}")
+
+
+class BatchedChainLQR:
+    """`batch` independent chain problems of horizon T, state dim n, control dim m."""
+
+    def __init__(self, n, m, T, batch, dtype=torch.float64, device="cuda:0"):
+        self._lib = load_library()
+        self.shape = ChainShape(n, m, T)
+        self.batch = int(batch)
+        self.dtype = dtype
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise LQRLibraryError("BatchedChainLQR needs a HIP device; there is no CPU path")
+        handle = ctypes.c_void_p()
+        _check(self._lib.sip_lqr_plan_create(_DTYPES[dtype], self.batch, T, n, m,
+                                             self.device.index or 0, ctypes.byref(handle)),
+               f"sip_lqr_plan_create(n={n}, m={m}, T={T}, {dtype})")
+        self._plan = handle
+        esize = torch.empty((), dtype=dtype).element_size()
+        assert self._lib.sip_lqr_mats_len(handle) == self.shape.mats_len
+        assert self._lib.sip_lqr_vecs_len(handle) == self.shape.vecs_len
+        assert self._lib.sip_lqr_gains_len(handle) == self.shape.gains_len
+        ws_elems = self._lib.sip_lqr_workspace_bytes(handle) // esize
+        self.workspace = torch.empty(ws_elems, dtype=dtype, device=self.device)
+        self.status = torch.zeros(self.batch, dtype=torch.int32, device=self.device)
+
+    @property
+    def kernel_name(self):
+        return self._lib.sip_lqr_kernel_name(self._plan).decode()
+
+    def empty_sol(self):
+        return torch.empty(self.batch, self.shape.vecs_len, dtype=self.dtype, device=self.device)
+
+    def empty_gains(self):
+        return torch.empty(self.batch, self.shape.gains_len, dtype=self.dtype, device=self.device)
+
+    def _ptr(self, t, rows, cols, name):
+        if t.dtype != self.dtype or t.device != self.device or not t.is_contiguous() \
+                or t.numel() != rows * cols:
+            raise ValueError(f"{name}: expected contiguous {self.dtype} [{rows}, {cols}] on {self.device}")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def factor_solve(self, mats, vecs, sol=None, gains=None, stream=None):
+        """One fused Riccati sweep (factor + solve) over the whole batch.
+
+        Asynchronous on `stream` (default: torch's current stream).  Returns
+        (sol, gains, status) device tensors in the packed chain layout.
+        """
+        s = self.shape
+        if sol is None:
+            sol = self.empty_sol()
+        if gains is None:
+            gains = self.empty_gains()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        _check(self._lib.sip_lqr_factor_solve(
+            self._plan, self._ptr(mats, self.batch, s.mats_len, "mats"),
+            self._ptr(vecs, self.batch, s.vecs_len, "vecs"),
+            self._ptr(sol, self.batch, s.vecs_len, "sol"),
+            self._ptr(gains, self.batch, s.gains_len, "gains"),
+            ctypes.c_void_p(self.status.data_ptr()),
+            ctypes.c_void_p(self.workspace.data_ptr()),
+            ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_factor_solve")
+        return sol, gains, self.status
+
+    def close(self):
+        if getattr(self, "_plan", None):
+            self._lib.sip_lqr_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

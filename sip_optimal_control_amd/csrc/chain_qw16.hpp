@@ -1,0 +1,401 @@
+// chain_qw16.hpp -- fp64 batched chain Riccati kernel, "quarter-wave" layout.
+//
+// One problem per 16-lane DPP row (4 problems per wavefront).  Lane c < N of a
+// row owns COLUMN c of every n x n / m x n matrix of its problem (rows live in
+// registers); lane N carries the affine ("vector") column, so the backward
+// affine sweep of LQR::solve (lqr.cpp:738-796: g, h, k, v) rides along in the
+// very same instructions that run the matrix recursion of
+// LQR::factor_with_status (lqr.cpp:645-731): [F|g] = W [A|t], [H|h] = [M^T|r] +
+// B^T [F|g], [K|k] = -G^{-1} [H|h], [V|v] = [Q|q] + A^T [F|g] + K^T [H|h].
+//
+// Cross-lane traffic is exclusively `v_fmac_f64_dpp ... row_newbcast:k`
+// (gfx90a+ DP-ALU DPP): a fused "broadcast lane k of my row, multiply,
+// accumulate" at the plain fp64 FMA issue rate -- no LDS round trip, no
+// ds_bpermute.  A p x q x r product costs p*q (or q*r) wave instructions for
+// four problems at once.
+//
+// Cholesky (Eigen::LLT of lqr.cpp:505,697) is right-looking on the full
+// symmetric storage: by symmetry lane j already holds row k of the trailing
+// matrix in its own register k, so the rank-1 update needs only the broadcast
+// of the scaled pivot column.  Pivot test d <= 0 reproduces Eigen's
+// NumericalIssue condition; statuses follow lqr.hpp:68-74 in the reference's
+// order (G before delta before F at a node; first failing node in postorder).
+//
+// The forward rollout (lqr.cpp:821-870) is restated with the identities
+//   y_c = g_c + W_c z,  x_c = z + c_c - delta_c o y_c,  z = A x + B u,
+// (g_c = v_c - W_c(delta_c o v_c - c_c) is the reference's own `g`,
+// lqr.cpp:778-781; the second line is the dynamics row of the KKT system),
+// so the only factor state spilled per node is [W | g].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "dpp_blocks_gen.hpp"
+
+namespace sipamd {
+
+template <int I, int E, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, E>(f);
+  }
+}
+// I, I-1, ..., E+1
+template <int I, int E, class F>
+__device__ __forceinline__ void sfor_down(F &&f) {
+  if constexpr (I > E) {
+    f(std::integral_constant<int, I>{});
+    sfor_down<I - 1, E>(f);
+  }
+}
+
+// Value of x in lane K of the caller's 16-lane row (compiler-scheduled
+// v_mov_b64_dpp; hipcc pads the DPP hazards of its own instructions).
+template <int K>
+__device__ __forceinline__ double bcast(double x) {
+  double und;
+  asm volatile("" : "=v"(und));
+  return __builtin_amdgcn_update_dpp(und, x, 0x150 + K, 0xf, 0xf, false);
+}
+
+// 1/sqrt(d): v_rsq_f64 seed + one third-order Newton step (full fp64).
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double s = d * y;
+  const double e = __builtin_fma(-s, y, 1.0);
+  const double t = __builtin_fma(0.375, e, 0.5);
+  return __builtin_fma(y * e, t, y);
+}
+
+// In-place lower Cholesky of the S x S symmetric matrix held one column per
+// lane (lanes c < S).  On exit lane j holds L(i,j) in A[i], i >= j; rinv[k] =
+// 1 / L(k,k) replicated in every lane.  Returns true iff a pivot was <= 0.
+template <int S>
+__device__ __forceinline__ bool chol_lower_dpp(double (&A)[S], double (&rinv)[S],
+                                               const int c) {
+  bool fail = false;
+  sfor<0, S>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    const double d = bcast<k>(A[k]);
+    fail |= (d <= 0.0);
+    const double y = rsqrt_nr(d);
+    rinv[k] = y;
+    const double lk = A[k] * y; // lane j > k: L(j,k) by symmetry
+    const double upd = (c > k && c < S) ? lk : 0.0;
+    const double ysel = (c == k) ? y : 1.0;
+    sfor<k, S>([&](auto ii) { A[decltype(ii)::value] *= ysel; });
+    // A(i,j) -= L(i,k) L(j,k), i > k, lanes j > k
+    rank1<S - k - 1, k, true, true>(A + k + 1, A + k + 1, upd);
+  });
+  return fail;
+}
+
+// X <- (L L^T)^{-1} X for X held one column per lane (any lane of the row may
+// carry a right-hand side), L / rinv as produced by chol_lower_dpp.
+template <int S>
+__device__ __forceinline__ void chol_solve_dpp(const double (&L)[S],
+                                               const double (&rinv)[S],
+                                               double (&X)[S]) {
+  sfor<0, S>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    X[j] *= rinv[j];
+    rank1<S - j - 1, j, true, true>(X + j + 1, L + j + 1, X[j]);
+  });
+  sfor_down<S - 1, -1>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    X[j] *= rinv[j];
+    spread<j, true, true>(X, L[j], X[j]); // X[i] -= L(j,i) X[j], i < j
+  });
+}
+
+template <int N, int M>
+struct ChainLayout {
+  // scalars per stage block (see include/sip_lqr_amd.h, "Packed chain layout")
+  static constexpr int NODE = N * N + N;               // Q | delta
+  static constexpr int EDGE = N * N + 2 * N * M + M * M; // A | B | M | R
+  static constexpr int VNODE = 2 * N;                  // q | c   (x | y)
+  static constexpr int VEDGE = M;                      // r       (u)
+  static constexpr int GAIN = M * N + M;               // K | k
+  static constexpr int WSN = N * N + N;                // W | g   (workspace)
+};
+
+// F_factor / W of one node (lqr.cpp:487-529).  V: column c of V (lanes < N).
+// dl: delta_c one per lane (1.0 on lanes >= N).  Returns pivot failure.
+template <int N>
+__device__ __forceinline__ bool node_factor(const double (&V)[N], const double dl,
+                                            const int c, const double (&E)[N],
+                                            double (&W)[N]) {
+  const double sdi = rsqrt_nr(dl); // sqrt_delta_inv, lqr.cpp:482
+  const double sd = dl * sdi;      // sqrt_delta,     lqr.cpp:481
+  double S[N], A[N], rinv[N];
+  sfor<0, N>([&](auto ii) { S[decltype(ii)::value] = 0.0; });
+  spread<N, false, true>(S, sd, sd); // S[r] = sd_r sd_c
+  sfor<0, N>([&](auto ii) {
+    constexpr int r = decltype(ii)::value;
+    A[r] = __builtin_fma(S[r], V[r], E[r]); // I + D^1/2 V D^1/2, lqr.cpp:497-503
+  });
+  const bool fail = chol_lower_dpp<N>(A, rinv, c);
+  double X[N];
+  sfor<0, N>([&](auto ii) { X[decltype(ii)::value] = E[decltype(ii)::value]; });
+  chol_solve_dpp<N>(A, rinv, X); // F^{-1}, lqr.cpp:516-519
+  sfor<0, N>([&](auto ii) { S[decltype(ii)::value] = 0.0; });
+  spread<N, false, true>(S, sdi, sdi);
+  sfor<0, N>([&](auto ii) {
+    constexpr int r = decltype(ii)::value;
+    W[r] = (E[r] - X[r]) * S[r]; // lqr.cpp:521-528
+  });
+  return fail;
+}
+
+template <int N, int M>
+__global__ __launch_bounds__(64) void chain_factor_solve_qw16(
+    const double *__restrict__ mats, const double *__restrict__ vecs,
+    double *__restrict__ sol, double *__restrict__ gains,
+    double *__restrict__ wsp, int *__restrict__ status, const long batch,
+    const int T) {
+  static_assert(N >= 1 && N <= 15, "vector lane needs N <= 15");
+  static_assert(M >= 1 && M <= 16, "");
+  using L = ChainLayout<N, M>;
+  constexpr int STG = L::NODE + L::EDGE;   // mats stage stride
+  constexpr int VSTG = L::VNODE + L::VEDGE; // vecs / sol stage stride
+
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 15;
+  long p = (long)blockIdx.x * 4 + (lane >> 4);
+  const bool valid = p < batch;
+  if (!valid)
+    p = batch - 1;
+  const bool isM = c < N;
+  const bool isV = c == N;
+  const int cm = isM ? c : N - 1; // clamped matrix column / row
+  const int cu = c < M ? c : M - 1; // clamped control column / row
+
+  const double *pm = mats + p * ((long)(T + 1) * L::NODE + (long)T * L::EDGE);
+  const double *pv = vecs + p * ((long)(T + 1) * L::VNODE + (long)T * L::VEDGE);
+  double *ps = sol + p * ((long)(T + 1) * L::VNODE + (long)T * L::VEDGE);
+  double *pg = gains + p * ((long)T * L::GAIN);
+  double *pw = wsp + p * ((long)(T + 1) * L::WSN);
+
+  double E[N];
+  sfor<0, N>([&](auto ii) {
+    constexpr int r = decltype(ii)::value;
+    E[r] = (c == r) ? 1.0 : 0.0;
+  });
+
+  int stat = 0;
+  double W[N], V[N], t[N], vch[N];
+
+  // Loads [Q_i | q_i] as the augmented column, delta_i per lane, and on the
+  // vector lane c_i, delta_i as columns.
+  auto load_node = [&](const int i, double(&Vq)[N], double &dl, double(&cv)[N],
+                       double(&dv)[N]) {
+    const double *nm = pm + (long)i * STG;
+    const double *nv = pv + (long)i * VSTG;
+    const double *src = isV ? nv : nm + cm * N;
+    sfor<0, N>([&](auto ii) {
+      constexpr int r = decltype(ii)::value;
+      Vq[r] = src[r];
+      cv[r] = nv[N + r];
+      dv[r] = nm[N * N + r];
+    });
+    const double d = nm[N * N + cm];
+    dl = isM ? d : 1.0;
+  };
+
+  // Common tail of every node: statuses, F/W (lqr.cpp:722-727 + 689), the
+  // vector-lane terms for the parent step, and the W spill.
+  auto finish_node = [&](const int i, const double dl, const double(&cv)[N],
+                         const double(&dv)[N]) {
+    const unsigned long long bad = __ballot(isM && dl <= 0.0);
+    const bool bad_row = ((bad >> (lane & 48)) & 0xffffull) != 0;
+    if (stat == 0 && bad_row)
+      stat = 1; // INVALID_DELTA
+    sfor<0, N>([&](auto ii) {
+      constexpr int r = decltype(ii)::value;
+      t[r] = cv[r] - dv[r] * V[r]; // -(f) = c - delta o v, lqr.cpp:778-779
+      vch[r] = V[r];
+    });
+    const bool ffail = node_factor<N>(V, dl, c, E, W);
+    if (stat == 0 && ffail)
+      stat = 2; // F_FACTORIZATION_FAILURE
+    if (valid && isM) {
+      double *wn = pw + (long)i * L::WSN + c * N;
+      sfor<0, N>([&](auto ii) { wn[decltype(ii)::value] = W[decltype(ii)::value]; });
+    }
+  };
+
+  // ---- terminal node (lqr.cpp:651-658 with no child edge) ----------------
+  {
+    double dl, cv[N], dv[N];
+    load_node(T, V, dl, cv, dv);
+    finish_node(T, dl, cv, dv);
+  }
+
+  // ---- backward recursion over edges i = T-1 .. 0 -------------------------
+  for (int i = T - 1; i >= 0; --i) {
+    const double *em = pm + (long)i * STG + L::NODE;
+    const double *ev = pv + (long)i * VSTG + L::VNODE;
+    double Acol[N], Bcol[N], MT[M], Rcol[M];
+    sfor<0, N>([&](auto ii) {
+      constexpr int r = decltype(ii)::value;
+      Acol[r] = em[cm * N + r];
+      Bcol[r] = em[N * N + cu * N + r];
+    });
+    sfor<0, M>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      // column c of M^T = row c of M; vector lane: r
+      MT[j] = isV ? ev[j] : em[N * N + N * M + j * N + cm];
+      Rcol[j] = em[N * N + 2 * N * M + cu * M + j];
+    });
+    double Vn[N], dl, cv[N], dv[N];
+    load_node(i, Vn, dl, cv, dv);
+
+    // [F | g - v_c] = W [A | t]   (lqr.cpp:703 and :780-781)
+    double F[N];
+    sfor<0, N>([&](auto ii) { F[decltype(ii)::value] = 0.0; });
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      const double a = isV ? t[k] : Acol[k];
+      rank1<N, k, false, true>(F, W, a);
+    });
+    sfor<0, N>([&](auto ii) {
+      constexpr int r = decltype(ii)::value;
+      F[r] += isV ? vch[r] : 0.0; // vector lane: g
+    });
+    if (valid && isV) {
+      double *gn = pw + (long)(i + 1) * L::WSN + N * N;
+      sfor<0, N>([&](auto ii) { gn[decltype(ii)::value] = F[decltype(ii)::value]; });
+    }
+
+    // H_child = B^T W (lqr.cpp:692); G = R + H_child B (lqr.cpp:693-694)
+    double Hc[M], G[M], rinvG[M];
+    sfor<0, M>([&](auto jj) { Hc[decltype(jj)::value] = 0.0; });
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      spread<M, false, true>(Hc, Bcol[k], W[k]);
+    });
+    sfor<0, M>([&](auto jj) { G[decltype(jj)::value] = Rcol[decltype(jj)::value]; });
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      rank1<M, k, false, true>(G, Hc, Bcol[k]);
+    });
+    const bool gfail = chol_lower_dpp<M>(G, rinvG, c); // lqr.cpp:696-701
+    if (stat == 0 && gfail)
+      stat = 3; // G_FACTORIZATION_FAILURE
+
+    // [H | h] = [M^T | r] + B^T [F | g]   (lqr.cpp:704-705, :783-784)
+    double H[M], K[M];
+    sfor<0, M>([&](auto jj) { H[decltype(jj)::value] = MT[decltype(jj)::value]; });
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      spread<M, false, true>(H, Bcol[k], F[k]);
+    });
+    // [K | k] = -G^{-1} [H | h]   (lqr.cpp:707-713, :785-791)
+    sfor<0, M>([&](auto jj) { K[decltype(jj)::value] = H[decltype(jj)::value]; });
+    chol_solve_dpp<M>(G, rinvG, K);
+    sfor<0, M>([&](auto jj) { K[decltype(jj)::value] = -K[decltype(jj)::value]; });
+    if (valid && c <= N) {
+      double *gi = pg + (long)i * L::GAIN + c * M;
+      sfor<0, M>([&](auto jj) { gi[decltype(jj)::value] = K[decltype(jj)::value]; });
+    }
+
+    // [V | v] = [Q | q] + A^T [F | g] + K^T [H | h]   (lqr.cpp:715-719, :793-794)
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      spread<N, false, true>(Vn, Acol[k], F[k]);
+    });
+    sfor<0, M>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      spread<N, false, true>(Vn, K[j], H[j]);
+    });
+    sfor<0, N>([&](auto ii) { V[decltype(ii)::value] = Vn[decltype(ii)::value]; });
+    finish_node(i, dl, cv, dv);
+  }
+
+  // ---- root: g_0 = v_0 + W_0 (c_0 - delta_0 o v_0)  (lqr.cpp:798-819) -----
+  {
+    double F[N];
+    sfor<0, N>([&](auto ii) { F[decltype(ii)::value] = 0.0; });
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      rank1<N, k, false, true>(F, W, t[k]);
+    });
+    if (valid && isV) {
+      double *gn = pw + N * N;
+      sfor<0, N>([&](auto ii) {
+        constexpr int r = decltype(ii)::value;
+        gn[r] = F[r] + vch[r];
+      });
+    }
+  }
+  if (valid && c == 0)
+    status[p] = stat;
+
+  // The rollout reads W / g / K / k written above by other lanes of this
+  // wave: workgroup-scope release/acquire (the block is one wavefront).
+  __syncthreads();
+
+  // ---- forward rollout (lqr.cpp:821-870); lane r < N owns row r ----------
+  double x, y;
+  {
+    const double gg = pw[N * N + cm];
+    const double cc = pv[N + cm];
+    const double dd = pm[N * N + cm];
+    y = gg;
+    x = cc - dd * gg;
+    if (valid && isM) {
+      ps[c] = x;
+      ps[N + c] = y;
+    }
+  }
+  for (int i = 0; i < T; ++i) {
+    const double *em = pm + (long)i * STG + L::NODE;
+    const double *nm1 = pm + (long)(i + 1) * STG;
+    const double *nv1 = pv + (long)(i + 1) * VSTG;
+    const double *gi = pg + (long)i * L::GAIN;
+    const double *wn = pw + (long)(i + 1) * L::WSN;
+    double KT[N], Arow[N], Brow[M], Wc[N];
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      KT[k] = gi[k * M + cu];
+      Arow[k] = em[k * N + cm];
+      Wc[k] = wn[cm * N + k]; // W symmetric: row r = column r
+    });
+    sfor<0, M>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      Brow[j] = em[N * N + j * N + cm];
+    });
+    const double kk0 = gi[N * M + cu];
+    const double gg = wn[N * N + cm];
+    const double cc = nv1[N + cm];
+    const double dd = nm1[N * N + cm];
+
+    double acc[4];
+    // u = k + K x  (lqr.cpp:856-857); lanes < M
+    acc[0] = kk0, acc[1] = 0.0, acc[2] = 0.0, acc[3] = 0.0;
+    dotv<N, true>(acc, x, KT);
+    const double u = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // z = A x + B u  (lqr.cpp:861-862)
+    acc[0] = 0.0, acc[1] = 0.0, acc[2] = 0.0, acc[3] = 0.0;
+    dotv<N, true>(acc, x, Arow);
+    dotv<M, true>(acc, u, Brow);
+    const double z = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // y_c = g_c + W_c z ; x_c = z + c_c - delta_c o y_c
+    acc[0] = gg, acc[1] = 0.0, acc[2] = 0.0, acc[3] = 0.0;
+    dotv<N, true>(acc, z, Wc);
+    y = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    x = z + (cc - dd * y);
+    if (valid) {
+      double *si = ps + (long)i * VSTG;
+      if (c < M)
+        si[2 * N + c] = u;
+      if (isM) {
+        si[VSTG + c] = x;
+        si[VSTG + N + c] = y;
+      }
+    }
+  }
+}
+
+} // namespace sipamd

@@ -1,0 +1,274 @@
+// sip_lqr_amd.hip -- C ABI (include/sip_lqr_amd.h) over the gfx950 kernels.
+// Host side of the drop-in boundary; no CPU compute path exists here.
+#include "../../include/sip_lqr_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "chain_qw16.hpp"
+
+struct sip_lqr_plan {
+  int dtype;
+  int64_t batch;
+  int T, n, m, device;
+  const char *kernel_name;
+  // fused factor+solve launcher
+  hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
+                          void *, void *, int32_t *, void *, hipStream_t);
+};
+
+namespace {
+
+template <int N, int M>
+hipError_t launch_qw16(const sip_lqr_plan *pl, const void *mats,
+                       const void *vecs, void *sol, void *gains,
+                       int32_t *status, void *ws, hipStream_t stream) {
+  const long batch = pl->batch;
+  const unsigned blocks = (unsigned)((batch + 3) / 4);
+  hipLaunchKernelGGL((sipamd::chain_factor_solve_qw16<N, M>), dim3(blocks),
+                     dim3(64), 0, stream, (const double *)mats,
+                     (const double *)vecs, (double *)sol, (double *)gains,
+                     (double *)ws, (int *)status, batch, pl->T);
+  return hipGetLastError();
+}
+
+struct KernelEntry {
+  int dtype, n, m;
+  const char *name;
+  hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
+                          void *, void *, int32_t *, void *, hipStream_t);
+};
+
+#define QW16(N, M)                                                             \
+  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ">/f64",           \
+    &launch_qw16<N, M> }
+
+const KernelEntry kKernels[] = {
+    QW16(12, 4), QW16(4, 2), QW16(1, 1), QW16(2, 1), QW16(3, 2), QW16(8, 3),
+};
+
+const KernelEntry *find_kernel(int dtype, int n, int m) {
+  for (const auto &k : kKernels)
+    if (k.dtype == dtype && k.n == n && k.m == m)
+      return &k;
+  return nullptr;
+}
+
+size_t scalar_size(const sip_lqr_plan *p) {
+  return p->dtype == SIP_LQR_F32 ? sizeof(float) : sizeof(double);
+}
+
+} // namespace
+
+extern "C" {
+
+int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
+                        int device, sip_lqr_plan **plan) {
+  if (plan == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  *plan = nullptr;
+  if (batch < 1 || T < 0 || n < 1 || m < 1 ||
+      (dtype != SIP_LQR_F64 && dtype != SIP_LQR_F32))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  const KernelEntry *k = find_kernel(dtype, n, m);
+  if (k == nullptr)
+    return SIP_LQR_ERR_UNSUPPORTED;
+  sip_lqr_plan *p = new (std::nothrow) sip_lqr_plan;
+  if (p == nullptr)
+    return SIP_LQR_ERR_ALLOC;
+  p->dtype = dtype;
+  p->batch = batch;
+  p->T = T;
+  p->n = n;
+  p->m = m;
+  p->device = device;
+  p->kernel_name = k->name;
+  p->launch_fs = k->launch_fs;
+  *plan = p;
+  return SIP_LQR_OK;
+}
+
+void sip_lqr_plan_destroy(sip_lqr_plan *plan) { delete plan; }
+
+size_t sip_lqr_mats_len(const sip_lqr_plan *p) {
+  const size_t n = p->n, m = p->m, T = p->T;
+  return (T + 1) * (n * n + n) + T * (n * n + 2 * n * m + m * m);
+}
+size_t sip_lqr_vecs_len(const sip_lqr_plan *p) {
+  const size_t n = p->n, m = p->m, T = p->T;
+  return (T + 1) * 2 * n + T * m;
+}
+size_t sip_lqr_gains_len(const sip_lqr_plan *p) {
+  const size_t n = p->n, m = p->m, T = p->T;
+  return T * (m * n + m);
+}
+size_t sip_lqr_mats_bytes(const sip_lqr_plan *p) {
+  return (size_t)p->batch * sip_lqr_mats_len(p) * scalar_size(p);
+}
+size_t sip_lqr_vecs_bytes(const sip_lqr_plan *p) {
+  return (size_t)p->batch * sip_lqr_vecs_len(p) * scalar_size(p);
+}
+size_t sip_lqr_sol_bytes(const sip_lqr_plan *p) {
+  return sip_lqr_vecs_bytes(p);
+}
+size_t sip_lqr_gains_bytes(const sip_lqr_plan *p) {
+  return (size_t)p->batch * sip_lqr_gains_len(p) * scalar_size(p);
+}
+size_t sip_lqr_status_bytes(const sip_lqr_plan *p) {
+  return (size_t)p->batch * sizeof(int32_t);
+}
+size_t sip_lqr_workspace_bytes(const sip_lqr_plan *p) {
+  const size_t n = p->n, T = p->T;
+  return (size_t)p->batch * (T + 1) * (n * n + n) * scalar_size(p);
+}
+
+} // extern "C"
+
+namespace {
+template <class S>
+void pack_one(const sip_lqr_plan *pl, int64_t p, double *const *Q,
+              double *const *M, double *const *R, double *const *q,
+              double *const *r, double *const *A, double *const *B,
+              double *const *c, double *const *delta, S *mats, S *vecs) {
+  const int n = pl->n, m = pl->m, T = pl->T;
+  S *mp = mats + (size_t)p * sip_lqr_mats_len(pl);
+  S *vp = vecs + (size_t)p * sip_lqr_vecs_len(pl);
+  auto put = [](S *&dst, const double *src, int count) {
+    for (int i = 0; i < count; ++i)
+      dst[i] = (S)src[i];
+    dst += count;
+  };
+  for (int i = 0; i <= T; ++i) {
+    put(mp, Q[i], n * n);
+    put(mp, delta[i], n);
+    put(vp, q[i], n);
+    put(vp, c[i], n);
+    if (i < T) {
+      put(mp, A[i], n * n);
+      put(mp, B[i], n * m);
+      put(mp, M[i], n * m);
+      put(mp, R[i], m * m);
+      put(vp, r[i], m);
+    }
+  }
+}
+
+template <class S>
+void unpack_sol(const sip_lqr_plan *pl, int64_t p, const S *sol,
+                double *const *x, double *const *u, double *const *y) {
+  const int n = pl->n, m = pl->m, T = pl->T;
+  const S *sp = sol + (size_t)p * sip_lqr_vecs_len(pl);
+  auto get = [](const S *&src, double *dst, int count) {
+    for (int i = 0; i < count; ++i)
+      dst[i] = (double)src[i];
+    src += count;
+  };
+  for (int i = 0; i <= T; ++i) {
+    get(sp, x[i], n);
+    get(sp, y[i], n);
+    if (i < T)
+      get(sp, u[i], m);
+  }
+}
+
+template <class S>
+void unpack_gain(const sip_lqr_plan *pl, int64_t p, const S *gains,
+                 double *const *K, double *const *k) {
+  const int n = pl->n, m = pl->m, T = pl->T;
+  const S *gp = gains + (size_t)p * sip_lqr_gains_len(pl);
+  for (int i = 0; i < T; ++i) {
+    for (int e = 0; e < m * n; ++e)
+      K[i][e] = (double)gp[e];
+    gp += m * n;
+    for (int e = 0; e < m; ++e)
+      k[i][e] = (double)gp[e];
+    gp += m;
+  }
+}
+} // namespace
+
+extern "C" {
+
+int sip_lqr_pack_problem(const sip_lqr_plan *plan, int64_t p, double *const *Q,
+                         double *const *M, double *const *R, double *const *q,
+                         double *const *r, double *const *A, double *const *B,
+                         double *const *c, double *const *delta,
+                         void *mats_host, void *vecs_host) {
+  if (plan == nullptr || p < 0 || p >= plan->batch || !Q || !q || !c ||
+      !delta || !mats_host || !vecs_host ||
+      (plan->T > 0 && (!M || !R || !r || !A || !B)))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (plan->dtype == SIP_LQR_F32)
+    pack_one<float>(plan, p, Q, M, R, q, r, A, B, c, delta, (float *)mats_host,
+                    (float *)vecs_host);
+  else
+    pack_one<double>(plan, p, Q, M, R, q, r, A, B, c, delta,
+                     (double *)mats_host, (double *)vecs_host);
+  return SIP_LQR_OK;
+}
+
+int sip_lqr_unpack_solution(const sip_lqr_plan *plan, int64_t p,
+                            const void *sol_host, double *const *x,
+                            double *const *u, double *const *y) {
+  if (plan == nullptr || p < 0 || p >= plan->batch || !sol_host || !x || !y ||
+      (plan->T > 0 && !u))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (plan->dtype == SIP_LQR_F32)
+    unpack_sol<float>(plan, p, (const float *)sol_host, x, u, y);
+  else
+    unpack_sol<double>(plan, p, (const double *)sol_host, x, u, y);
+  return SIP_LQR_OK;
+}
+
+int sip_lqr_unpack_gains(const sip_lqr_plan *plan, int64_t p,
+                         const void *gains_host, double *const *K,
+                         double *const *k) {
+  if (plan == nullptr || p < 0 || p >= plan->batch || !gains_host ||
+      (plan->T > 0 && (!K || !k)))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (plan->dtype == SIP_LQR_F32)
+    unpack_gain<float>(plan, p, (const float *)gains_host, K, k);
+  else
+    unpack_gain<double>(plan, p, (const double *)gains_host, K, k);
+  return SIP_LQR_OK;
+}
+
+int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
+                         const void *d_vecs, void *d_sol, void *d_gains,
+                         int32_t *d_status, void *d_workspace, void *stream) {
+  if (plan == nullptr || !d_mats || !d_vecs || !d_sol || !d_status ||
+      !d_workspace || (plan->T > 0 && !d_gains))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (plan->launch_fs == nullptr)
+    return SIP_LQR_ERR_UNSUPPORTED;
+  const hipError_t e = plan->launch_fs(plan, d_mats, d_vecs, d_sol, d_gains,
+                                       d_status, d_workspace,
+                                       (hipStream_t)stream);
+  if (e != hipSuccess) {
+    std::fprintf(stderr, "sip_lqr_factor_solve: %s\n", hipGetErrorString(e));
+    return SIP_LQR_ERR_HIP;
+  }
+  return SIP_LQR_OK;
+}
+
+int sip_lqr_factor(const sip_lqr_plan *, const void *, void *, int32_t *,
+                   void *, void *) {
+  return SIP_LQR_ERR_UNSUPPORTED; // split factor/solve kernels: not built yet
+}
+
+int sip_lqr_solve(const sip_lqr_plan *, const void *, const void *, void *,
+                  void *, void *, void *) {
+  return SIP_LQR_ERR_UNSUPPORTED;
+}
+
+const char *sip_lqr_kernel_name(const sip_lqr_plan *plan) {
+  return plan ? plan->kernel_name : "";
+}
+
+const char *sip_lqr_version(void) { return "sip_lqr_amd 0.1 (gfx950)"; }
+
+} // extern "C"
