@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Riccati sweeps/sec of the MI355X batched regularized-LQR path.
+
+One "step" = one fused factor+solve sweep (the loop body of the reference's
+BM_LQRFactorSolve, benchmarks/lqr_benchmark.cpp:653-663) over one batch of
+synthetic chain problems (recipe of lqr_benchmark.cpp:61-98) already resident
+in HBM, per GPU; for N > 1 GPUs the batch is sharded by problem (weak scaling:
+every rank owns `batch` problems) and each step's gains (K, k) are all-gathered
+over RCCL/xGMI, pipelined against the next step's compute.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs: name -> (batch, T, n, m, dtype)
+WORKLOADS = {
+    "c1": (1, 20, 4, 2, "f64"),
+    "c2": (1024, 50, 12, 4, "f64"),
+    "c3": (4096, 50, 12, 4, "f64"),
+    "c4": (4096, 100, 32, 8, "f32"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="multi-GPU: skip the RCCL all-gather of the gains")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="target wall time of each cpu_baseline leg")
+    return ap.parse_args()
+
+
+def usable_cores():
+    """Host cores this process may really use: min(affinity, cgroup CPU quota)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("SIP_LQR_BENCH_CORES")
+    if env:
+        cores = int(env)
+    return max(1, cores)
+
+
+def cpu_baseline(shape, mats, vecs, seconds):
+    """Time the CPU oracle ("port": Eigen-free restatement of lqr.cpp, see
+    oracle/lqr_oracle.h) on a bounded sample of the same workload."""
+    from oracle import oracle
+    import numpy as np
+    cores = usable_cores()
+    n, m, T = shape.n, shape.m, shape.T
+    sample = min(mats.shape[0], max(256, 16 * cores))
+    hm = mats[:sample].cpu().numpy().astype(np.float64)
+    hv = vecs[:sample].cpu().numpy().astype(np.float64)
+    oracle.chain_batch(n, m, T, hm[:8], hv[:8], threads=1, want_gains=True)  # warm
+
+    def timed(threads, budget):
+        # calibrate, then repeat the sample until ~budget seconds have passed
+        t0 = time.perf_counter()
+        oracle.chain_batch(n, m, T, hm, hv, threads=threads)
+        once = time.perf_counter() - t0
+        reps = max(1, int(budget / max(once, 1e-6)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.chain_batch(n, m, T, hm, hv, threads=threads)
+        dt = time.perf_counter() - t0
+        return sample * reps / dt, reps
+
+    one, reps1 = timed(1, seconds * 0.4)
+    allc, repsn = timed(cores, seconds * 0.6)
+    return {
+        "value": allc, "unit": "sweeps/s", "cores": cores, "kind": "port",
+        "value_1core": one,
+        "sample": f"{sample} problems of the same synthetic batch, repeated {repsn}x on {cores} "
+                  f"threads (OpenMP over problems) and {reps1}x on 1 thread; oracle/lqr_oracle.c "
+                  f"(Eigen-free restatement of lqr.cpp; the Eigen reference binary cannot be built here)",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py ...`")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    batch, T, n, m, dt = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    if dt != "f64":
+        raise SystemExit(f"workload {args.workload}: dtype {dt} has no kernel yet")
+    dtype = torch.float64
+    shape = ChainShape(n, m, T)
+    mats, vecs = synthetic.make_chain_batch(shape, batch, seed=1234 + rank, device=device, dtype=dtype)
+    solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device=device)
+    sol = solver.empty_sol()
+    gains = [solver.empty_gains(), solver.empty_gains()]
+    gather = world > 1 and not args.no_gather
+    if gather:
+        all_gains = [torch.empty(world * batch, shape.gains_len, dtype=dtype, device=device)
+                     for _ in range(2)]
+        comm_stream = torch.cuda.Stream(device)
+        gathered = [None, None]
+
+    compute = torch.cuda.current_stream(device)
+    kernel_events = []
+
+    def step(i, timed):
+        b = i & 1
+        if gather and gathered[b] is not None:
+            compute.wait_event(gathered[b])  # gains[b] is still being read by the gather of step i-2
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(compute)
+        solver.factor_solve(mats, vecs, sol, gains[b])
+        if timed:
+            e1.record(compute)
+            kernel_events.append((e0, e1))
+        if gather:
+            done = torch.cuda.Event()
+            done.record(compute)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(done)
+                dist.all_gather_into_tensor(all_gains[b], gains[b])
+                g = torch.cuda.Event()
+                g.record(comm_stream)
+            gathered[b] = g
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i, False)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    if gather:
+        for g in gathered:
+            if g is not None:
+                compute.wait_event(g)
+    torch.cuda.synchronize(device)
+    elapsed_local = time.perf_counter() - t0
+    fence()
+    el = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    status_ok = bool((solver.status == 0).all().item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))
+
+    if rank == 0:
+        alg_bytes = shape.algorithmic_bytes(8)
+        achieved = alg_bytes * batch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath)).get(f"{args.workload}:{solver.kernel_name}")
+                traffic = rec["hbm_bytes_per_launch"] if rec else None
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Riccati sweeps/sec (backward+forward)",
+            "value": world * batch * args.steps / elapsed,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dt,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: batch={batch}/GPU x horizon={T}, nx={n}, nu={m}, {dt}, "
+                            f"chain, fused factor+solve" + (", RCCL all-gather of gains" if gather else ""),
+                "global_batch": world * batch, "horizon": T, "nx": n, "nu": m,
+                "parallelism": f"batch-sharded x{world}" + ("+allgather(K,k)" if gather else ""),
+                "kernel": solver.kernel_name, "all_status_success": status_ok,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes * batch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(shape, mats, vecs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
