@@ -15,7 +15,8 @@ class LQRLibraryError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", _LIB_NAME)
+    # SIP_LQR_LIB: diagnostic builds (tools/diag_build.sh) only.
+    return os.environ.get("SIP_LQR_LIB") or os.path.join(_HERE, "lib", _LIB_NAME)
 
 
 # name -> (restype, argtypes); mirrors include/sip_lqr_amd.h one to one.

@@ -148,34 +148,145 @@ __device__ __forceinline__ bool node_factor(const double (&V)[N], const double d
   return fail;
 }
 
-template <int N, int M>
+typedef __attribute__((address_space(3))) char lds_char;
+typedef const __attribute__((address_space(3))) double lds_cdouble;
+
+// Diagnostic build only (-DSIP_LQR_STAMPS, tools/diag_build.sh): shader-clock
+// stamps around the phases of a wave; the product build executes none.
+#ifdef SIP_LQR_STAMPS
+#define SIP_STAMP(var)                                                         \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+#define SIP_STAMP_ARG , unsigned long long *__restrict__ stamps
+#else
+#define SIP_STAMP(var)                                                         \
+  do {                                                                         \
+  } while (0)
+#define SIP_STAMP_ARG
+#endif
+
+// LDS-DMA staging of one contiguous per-problem region (PIECES 16-byte pieces
+// per problem) for the 4 problems of a wave: `global_load_lds_dwordx4` writes
+// LDS as wave-uniform base + lane*16, so instruction j fills image bytes
+// [1024 j, 1024 j + 1024) and each lane picks the global piece that belongs
+// there.  Image: problem rr of the wave at byte rr * PIECES * 16.
+template <int PIECES>
+struct StageDma {
+  static constexpr int INSTR = (4 * PIECES + 63) / 64;
+  static constexpr int BYTES = INSTR * 1024;
+  unsigned off[INSTR > 0 ? INSTR : 1];
+  __device__ __forceinline__ void init(const int lane,
+                                       const unsigned problem_stride_bytes,
+                                       const unsigned max_rel) {
+    sfor<0, INSTR>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      const unsigned q = j * 64 + lane;
+      unsigned rr = q / PIECES;
+      const unsigned within = q - rr * PIECES;
+      rr = rr < max_rel ? rr : max_rel;
+      off[j] = rr * problem_stride_bytes + within * 16u;
+    });
+  }
+  // base: wave-uniform pointer to the region of the wave's first problem.
+  __device__ __forceinline__ void issue(const char *base, lds_char *dst,
+                                        const int lane) const {
+    sfor<0, INSTR>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      if constexpr (j * 64 + 63 < 4 * PIECES) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(base + off[j]),
+            (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0,
+            0);
+      } else {
+        if (j * 64 + lane < 4 * PIECES)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(base + off[j]),
+              (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
+              0, 0);
+      }
+    });
+  }
+};
+
+// Byte sizes of the LDS images of the staged kernel (one wave per block).
+template <int N, int M, bool WPACK>
+struct StagedCfg {
+  using L = ChainLayout<N, M>;
+  static constexpr int WSN = // W | g, even number of scalars
+      WPACK ? ((N * (N + 1) / 2 + N + 1) / 2) * 2 : L::WSN;
+  // backward: whole stage block of mats + of vecs
+  using BM = StageDma<(L::NODE + L::EDGE) / 2>;
+  using BV = StageDma<(L::VNODE + L::VEDGE) / 2>;
+  static constexpr int B_BYTES = BM::BYTES + BV::BYTES;
+  // forward: A|B, gains, W|g of the child, c and delta of the child
+  using FA = StageDma<(N * N + N * M) / 2>;
+  using FG = StageDma<L::GAIN / 2>;
+  using FW = StageDma<WSN / 2>;
+  using FC = StageDma<N / 2>;
+  static constexpr int F_BYTES =
+      FA::BYTES + FG::BYTES + FW::BYTES + 2 * FC::BYTES;
+  static constexpr int NBUF = 2;
+  static constexpr int LDS_BYTES =
+      NBUF * (B_BYTES > F_BYTES ? B_BYTES : F_BYTES);
+  static constexpr bool OK = (N % 2 == 0) && (M % 2 == 0);
+};
+
+// Fused factor + solve.  STAGED: stage blocks travel HBM -> LDS by LDS-DMA one
+// stage ahead of the arithmetic (needs N and M even: 16-byte pieces);
+// otherwise every lane loads its columns straight from global memory.
+// WPACK: spill only the lower triangle of the symmetric W.
+template <int N, int M, bool STAGED, bool WPACK>
 __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     const double *__restrict__ mats, const double *__restrict__ vecs,
     double *__restrict__ sol, double *__restrict__ gains,
     double *__restrict__ wsp, int *__restrict__ status, const long batch,
-    const int T) {
+    const int T SIP_STAMP_ARG) {
   static_assert(N >= 1 && N <= 15, "vector lane needs N <= 15");
   static_assert(M >= 1 && M <= 16, "");
   using L = ChainLayout<N, M>;
-  constexpr int STG = L::NODE + L::EDGE;   // mats stage stride
+  using C = StagedCfg<N, M, WPACK>;
+  unsigned long long ts_begin = 0, ts_term = 0, ts_bwd = 0, ts_root = 0,
+                     ts_end = 0, ts_a = 0, ts_b = 0, acc_bwait = 0,
+                     acc_fwait = 0;
+  (void)ts_begin, (void)ts_term, (void)ts_bwd, (void)ts_root, (void)ts_end,
+      (void)ts_a, (void)ts_b, (void)acc_bwait, (void)acc_fwait;
+  SIP_STAMP(ts_begin);
+  static_assert(!STAGED || C::OK, "staged kernel needs even N and M");
+  constexpr int STG = L::NODE + L::EDGE;    // mats stage stride
   constexpr int VSTG = L::VNODE + L::VEDGE; // vecs / sol stage stride
+  constexpr int WSN = C::WSN;
+  constexpr int WG = WPACK ? N * (N + 1) / 2 : N * N; // offset of g in a slot
+
+  extern __shared__ double lds_raw[];
+  lds_char *const lds = (lds_char *)lds_raw;
 
   const int lane = threadIdx.x & 63;
   const int c = lane & 15;
-  long p = (long)blockIdx.x * 4 + (lane >> 4);
+  const int rr = lane >> 4;
+  const long p0 = (long)blockIdx.x * 4;
+  long p = p0 + rr;
   const bool valid = p < batch;
   if (!valid)
     p = batch - 1;
   const bool isM = c < N;
   const bool isV = c == N;
-  const int cm = isM ? c : N - 1; // clamped matrix column / row
+  const int cm = isM ? c : N - 1;   // clamped matrix column / row
   const int cu = c < M ? c : M - 1; // clamped control column / row
 
-  const double *pm = mats + p * ((long)(T + 1) * L::NODE + (long)T * L::EDGE);
-  const double *pv = vecs + p * ((long)(T + 1) * L::VNODE + (long)T * L::VEDGE);
-  double *ps = sol + p * ((long)(T + 1) * L::VNODE + (long)T * L::VEDGE);
-  double *pg = gains + p * ((long)T * L::GAIN);
-  double *pw = wsp + p * ((long)(T + 1) * L::WSN);
+  const long mats_len = (long)(T + 1) * L::NODE + (long)T * L::EDGE;
+  const long vecs_len = (long)(T + 1) * L::VNODE + (long)T * L::VEDGE;
+  const long gains_len = (long)T * L::GAIN;
+  const long ws_len = (long)(T + 1) * WSN;
+  const double *pm = mats + p * mats_len;
+  const double *pv = vecs + p * vecs_len;
+  double *ps = sol + p * vecs_len;
+  double *pg = gains + p * gains_len;
+  double *pw = wsp + p * ws_len;
+  const unsigned max_rel =
+      (unsigned)((batch - 1 - p0) < 3 ? (batch - 1 - p0) : 3);
 
   double E[N];
   sfor<0, N>([&](auto ii) {
@@ -187,12 +298,10 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   double W[N], V[N], t[N], vch[N];
 
   // Loads [Q_i | q_i] as the augmented column, delta_i per lane, and on the
-  // vector lane c_i, delta_i as columns.
-  auto load_node = [&](const int i, double(&Vq)[N], double &dl, double(&cv)[N],
-                       double(&dv)[N]) {
-    const double *nm = pm + (long)i * STG;
-    const double *nv = pv + (long)i * VSTG;
-    const double *src = isV ? nv : nm + cm * N;
+  // vector lane c_i, delta_i as columns.  nm / nv: stage block of mats / vecs.
+  auto load_node = [&](auto nm, auto nv, double(&Vq)[N], double &dl,
+                       double(&cv)[N], double(&dv)[N]) {
+    auto src = isV ? nv : nm + cm * N;
     sfor<0, N>([&](auto ii) {
       constexpr int r = decltype(ii)::value;
       Vq[r] = src[r];
@@ -220,37 +329,27 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     if (stat == 0 && ffail)
       stat = 2; // F_FACTORIZATION_FAILURE
     if (valid && isM) {
-      double *wn = pw + (long)i * L::WSN + c * N;
-      sfor<0, N>([&](auto ii) { wn[decltype(ii)::value] = W[decltype(ii)::value]; });
+      if constexpr (WPACK) {
+        // column c of the lower triangle: rows c..N-1, packed by columns
+        double *wn = pw + (long)i * WSN + (c * N - (c * (c - 1)) / 2 - c);
+        sfor<0, N>([&](auto ii) {
+          constexpr int r = decltype(ii)::value;
+          if (r >= c)
+            wn[r] = W[r];
+        });
+      } else {
+        double *wn = pw + (long)i * WSN + c * N;
+        sfor<0, N>(
+            [&](auto ii) { wn[decltype(ii)::value] = W[decltype(ii)::value]; });
+      }
     }
   };
 
-  // ---- terminal node (lqr.cpp:651-658 with no child edge) ----------------
-  {
-    double dl, cv[N], dv[N];
-    load_node(T, V, dl, cv, dv);
-    finish_node(T, dl, cv, dv);
-  }
-
-  // ---- backward recursion over edges i = T-1 .. 0 -------------------------
-  for (int i = T - 1; i >= 0; --i) {
-    const double *em = pm + (long)i * STG + L::NODE;
-    const double *ev = pv + (long)i * VSTG + L::VNODE;
-    double Acol[N], Bcol[N], MT[M], Rcol[M];
-    sfor<0, N>([&](auto ii) {
-      constexpr int r = decltype(ii)::value;
-      Acol[r] = em[cm * N + r];
-      Bcol[r] = em[N * N + cu * N + r];
-    });
-    sfor<0, M>([&](auto jj) {
-      constexpr int j = decltype(jj)::value;
-      // column c of M^T = row c of M; vector lane: r
-      MT[j] = isV ? ev[j] : em[N * N + N * M + j * N + cm];
-      Rcol[j] = em[N * N + 2 * N * M + cu * M + j];
-    });
-    double Vn[N], dl, cv[N], dv[N];
-    load_node(i, Vn, dl, cv, dv);
-
+  // One backward step over edge i (lqr.cpp:660-720 and :746-795), all inputs
+  // already in registers.
+  auto backward_edge = [&](const int i, const double(&Acol)[N],
+                           const double(&Bcol)[N], const double(&MT)[M],
+                           const double(&Rcol)[M], double(&Vn)[N]) {
     // [F | g - v_c] = W [A | t]   (lqr.cpp:703 and :780-781)
     double F[N];
     sfor<0, N>([&](auto ii) { F[decltype(ii)::value] = 0.0; });
@@ -264,8 +363,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       F[r] += isV ? vch[r] : 0.0; // vector lane: g
     });
     if (valid && isV) {
-      double *gn = pw + (long)(i + 1) * L::WSN + N * N;
-      sfor<0, N>([&](auto ii) { gn[decltype(ii)::value] = F[decltype(ii)::value]; });
+      double *gn = pw + (long)(i + 1) * WSN + WG;
+      sfor<0, N>(
+          [&](auto ii) { gn[decltype(ii)::value] = F[decltype(ii)::value]; });
     }
 
     // H_child = B^T W (lqr.cpp:692); G = R + H_child B (lqr.cpp:693-694)
@@ -275,7 +375,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       constexpr int k = decltype(kk)::value;
       spread<M, false, true>(Hc, Bcol[k], W[k]);
     });
-    sfor<0, M>([&](auto jj) { G[decltype(jj)::value] = Rcol[decltype(jj)::value]; });
+    sfor<0, M>(
+        [&](auto jj) { G[decltype(jj)::value] = Rcol[decltype(jj)::value]; });
     sfor<0, N>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
       rank1<M, k, false, true>(G, Hc, Bcol[k]);
@@ -286,21 +387,25 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
 
     // [H | h] = [M^T | r] + B^T [F | g]   (lqr.cpp:704-705, :783-784)
     double H[M], K[M];
-    sfor<0, M>([&](auto jj) { H[decltype(jj)::value] = MT[decltype(jj)::value]; });
+    sfor<0, M>(
+        [&](auto jj) { H[decltype(jj)::value] = MT[decltype(jj)::value]; });
     sfor<0, N>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
       spread<M, false, true>(H, Bcol[k], F[k]);
     });
     // [K | k] = -G^{-1} [H | h]   (lqr.cpp:707-713, :785-791)
-    sfor<0, M>([&](auto jj) { K[decltype(jj)::value] = H[decltype(jj)::value]; });
+    sfor<0, M>(
+        [&](auto jj) { K[decltype(jj)::value] = H[decltype(jj)::value]; });
     chol_solve_dpp<M>(G, rinvG, K);
-    sfor<0, M>([&](auto jj) { K[decltype(jj)::value] = -K[decltype(jj)::value]; });
+    sfor<0, M>(
+        [&](auto jj) { K[decltype(jj)::value] = -K[decltype(jj)::value]; });
     if (valid && c <= N) {
       double *gi = pg + (long)i * L::GAIN + c * M;
-      sfor<0, M>([&](auto jj) { gi[decltype(jj)::value] = K[decltype(jj)::value]; });
+      sfor<0, M>(
+          [&](auto jj) { gi[decltype(jj)::value] = K[decltype(jj)::value]; });
     }
 
-    // [V | v] = [Q | q] + A^T [F | g] + K^T [H | h]   (lqr.cpp:715-719, :793-794)
+    // [V | v] = [Q | q] + A^T [F | g] + K^T [H | h]  (lqr.cpp:715-719,:793-794)
     sfor<0, N>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
       spread<N, false, true>(Vn, Acol[k], F[k]);
@@ -309,10 +414,82 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       constexpr int j = decltype(jj)::value;
       spread<N, false, true>(Vn, K[j], H[j]);
     });
-    sfor<0, N>([&](auto ii) { V[decltype(ii)::value] = Vn[decltype(ii)::value]; });
+    sfor<0, N>(
+        [&](auto ii) { V[decltype(ii)::value] = Vn[decltype(ii)::value]; });
+  };
+
+  // Reads edge i from its stage block (em: edge part of mats, ev: r of vecs).
+  auto load_edge = [&](auto em, auto ev, double(&Acol)[N], double(&Bcol)[N],
+                       double(&MT)[M], double(&Rcol)[M]) {
+    sfor<0, N>([&](auto ii) {
+      constexpr int r = decltype(ii)::value;
+      Acol[r] = em[cm * N + r];
+      Bcol[r] = em[N * N + cu * N + r];
+    });
+    auto msrc = isV ? ev : em + (N * N + N * M + cm);
+    sfor<0, M>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      // column c of M^T = row c of M; vector lane: r
+      MT[j] = isV ? msrc[j] : msrc[j * N];
+      Rcol[j] = em[N * N + 2 * N * M + cu * M + j];
+    });
+  };
+
+  // ---- terminal node (lqr.cpp:651-658 with no child edge) ----------------
+  typename C::BM dma_bm;
+  typename C::BV dma_bv;
+  if constexpr (STAGED) {
+    dma_bm.init(lane, (unsigned)(mats_len * 8), max_rel);
+    dma_bv.init(lane, (unsigned)(vecs_len * 8), max_rel);
+    if (T > 0) {
+      lds_char *buf = lds + ((T - 1) & 1) * C::B_BYTES;
+      dma_bm.issue((const char *)(mats + p0 * mats_len + (long)(T - 1) * STG),
+                   buf, lane);
+      dma_bv.issue((const char *)(vecs + p0 * vecs_len + (long)(T - 1) * VSTG),
+                   buf + C::BM::BYTES, lane);
+    }
+  }
+  {
+    double dl, cv[N], dv[N];
+    load_node(pm + (long)T * STG, pv + (long)T * VSTG, V, dl, cv, dv);
+    finish_node(T, dl, cv, dv);
+  }
+  SIP_STAMP(ts_term);
+
+  // ---- backward recursion over edges i = T-1 .. 0 -------------------------
+  for (int i = T - 1; i >= 0; --i) {
+    double Acol[N], Bcol[N], MT[M], Rcol[M];
+    double Vn[N], dl, cv[N], dv[N];
+    SIP_STAMP(ts_a);
+    if constexpr (STAGED) {
+      lds_char *buf = lds + (i & 1) * C::B_BYTES;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stage i has landed
+      SIP_STAMP(ts_b);
+      acc_bwait += ts_b - ts_a;
+      lds_cdouble *nm = (lds_cdouble *)(buf + rr * (STG * 8));
+      lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + rr * (VSTG * 8));
+      load_edge(nm + L::NODE, nv + L::VNODE, Acol, Bcol, MT, Rcol);
+      load_node(nm, nv, Vn, dl, cv, dv);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all of it in VGPRs
+      if (i > 0) { // next stage streams in behind this stage's arithmetic
+        lds_char *nbuf = lds + ((i - 1) & 1) * C::B_BYTES;
+        dma_bm.issue((const char *)(mats + p0 * mats_len + (long)(i - 1) * STG),
+                     nbuf, lane);
+        dma_bv.issue(
+            (const char *)(vecs + p0 * vecs_len + (long)(i - 1) * VSTG),
+            nbuf + C::BM::BYTES, lane);
+      }
+    } else {
+      const double *nm = pm + (long)i * STG;
+      const double *nv = pv + (long)i * VSTG;
+      load_edge(nm + L::NODE, nv + L::VNODE, Acol, Bcol, MT, Rcol);
+      load_node(nm, nv, Vn, dl, cv, dv);
+    }
+    backward_edge(i, Acol, Bcol, MT, Rcol, Vn);
     finish_node(i, dl, cv, dv);
   }
 
+  SIP_STAMP(ts_bwd);
   // ---- root: g_0 = v_0 + W_0 (c_0 - delta_0 o v_0)  (lqr.cpp:798-819) -----
   {
     double F[N];
@@ -322,7 +499,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       rank1<N, k, false, true>(F, W, t[k]);
     });
     if (valid && isV) {
-      double *gn = pw + N * N;
+      double *gn = pw + WG;
       sfor<0, N>([&](auto ii) {
         constexpr int r = decltype(ii)::value;
         gn[r] = F[r] + vch[r];
@@ -335,11 +512,54 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   // The rollout reads W / g / K / k written above by other lanes of this
   // wave: workgroup-scope release/acquire (the block is one wavefront).
   __syncthreads();
+  SIP_STAMP(ts_root);
 
   // ---- forward rollout (lqr.cpp:821-870); lane r < N owns row r ----------
+  // Offsets of W(r, k), k = 0..N-1, inside a [W | g] slot.
+  int woff[N];
+  sfor<0, N>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    if constexpr (WPACK) {
+      const int lo = k < cm ? k : cm, hi = k < cm ? cm : k; // W(hi, lo)
+      woff[k] = lo * N - (lo * (lo - 1)) / 2 + (hi - lo);
+    } else {
+      woff[k] = cm * N + k; // W symmetric: row r = column r
+    }
+  });
+
+  typename C::FA dma_fa;
+  typename C::FG dma_fg;
+  typename C::FW dma_fw;
+  typename C::FC dma_fc;
+  typename C::FC dma_fd; // delta lives in mats: its own problem stride
+  if constexpr (STAGED) {
+    dma_fa.init(lane, (unsigned)(mats_len * 8), max_rel);
+    dma_fg.init(lane, (unsigned)(gains_len * 8), max_rel);
+    dma_fw.init(lane, (unsigned)(ws_len * 8), max_rel);
+    dma_fc.init(lane, (unsigned)(vecs_len * 8), max_rel);
+    dma_fd.init(lane, (unsigned)(mats_len * 8), max_rel);
+  }
+  auto issue_forward = [&](const int i, lds_char *buf) {
+    dma_fa.issue((const char *)(mats + p0 * mats_len + (long)i * STG + L::NODE),
+                 buf, lane);
+    dma_fg.issue((const char *)(gains + p0 * gains_len + (long)i * L::GAIN),
+                 buf + C::FA::BYTES, lane);
+    dma_fw.issue((const char *)(wsp + p0 * ws_len + (long)(i + 1) * WSN),
+                 buf + C::FA::BYTES + C::FG::BYTES, lane);
+    dma_fc.issue((const char *)(vecs + p0 * vecs_len + (long)(i + 1) * VSTG + N),
+                 buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES, lane);
+    dma_fd.issue(
+        (const char *)(mats + p0 * mats_len + (long)(i + 1) * STG + N * N),
+        buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES + C::FC::BYTES, lane);
+  };
+  if constexpr (STAGED) {
+    if (T > 0)
+      issue_forward(0, lds);
+  }
+
   double x, y;
   {
-    const double gg = pw[N * N + cm];
+    const double gg = pw[WG + cm];
     const double cc = pv[N + cm];
     const double dd = pm[N * N + cm];
     y = gg;
@@ -350,26 +570,45 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     }
   }
   for (int i = 0; i < T; ++i) {
-    const double *em = pm + (long)i * STG + L::NODE;
-    const double *nm1 = pm + (long)(i + 1) * STG;
-    const double *nv1 = pv + (long)(i + 1) * VSTG;
-    const double *gi = pg + (long)i * L::GAIN;
-    const double *wn = pw + (long)(i + 1) * L::WSN;
     double KT[N], Arow[N], Brow[M], Wc[N];
-    sfor<0, N>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      KT[k] = gi[k * M + cu];
-      Arow[k] = em[k * N + cm];
-      Wc[k] = wn[cm * N + k]; // W symmetric: row r = column r
-    });
-    sfor<0, M>([&](auto jj) {
-      constexpr int j = decltype(jj)::value;
-      Brow[j] = em[N * N + j * N + cm];
-    });
-    const double kk0 = gi[N * M + cu];
-    const double gg = wn[N * N + cm];
-    const double cc = nv1[N + cm];
-    const double dd = nm1[N * N + cm];
+    double kk0, gg, cc, dd;
+    auto read_stage = [&](auto em, auto gi, auto wn, auto cp, auto dp) {
+      sfor<0, N>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        KT[k] = gi[k * M + cu];
+        Arow[k] = em[k * N + cm];
+        Wc[k] = wn[woff[k]];
+      });
+      sfor<0, M>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        Brow[j] = em[N * N + j * N + cm];
+      });
+      kk0 = gi[N * M + cu];
+      gg = wn[WG + cm];
+      cc = cp[cm];
+      dd = dp[cm];
+    };
+    SIP_STAMP(ts_a);
+    if constexpr (STAGED) {
+      lds_char *buf = lds + (i & 1) * C::F_BYTES;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SIP_STAMP(ts_b);
+      acc_fwait += ts_b - ts_a;
+      lds_char *b1 = buf + C::FA::BYTES, *b2 = b1 + C::FG::BYTES,
+               *b3 = b2 + C::FW::BYTES, *b4 = b3 + C::FC::BYTES;
+      read_stage((lds_cdouble *)(buf + rr * ((N * N + N * M) * 8)),
+                 (lds_cdouble *)(b1 + rr * (L::GAIN * 8)),
+                 (lds_cdouble *)(b2 + rr * (WSN * 8)),
+                 (lds_cdouble *)(b3 + rr * (N * 8)),
+                 (lds_cdouble *)(b4 + rr * (N * 8)));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (i + 1 < T)
+        issue_forward(i + 1, lds + ((i + 1) & 1) * C::F_BYTES);
+    } else {
+      read_stage(pm + (long)i * STG + L::NODE, pg + (long)i * L::GAIN,
+                 pw + (long)(i + 1) * WSN, pv + (long)(i + 1) * VSTG + N,
+                 pm + (long)(i + 1) * STG + N * N);
+    }
 
     double acc[4];
     // u = k + K x  (lqr.cpp:856-857); lanes < M
@@ -396,6 +635,15 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       }
     }
   }
+#ifdef SIP_LQR_STAMPS
+  SIP_STAMP(ts_end);
+  if (stamps != nullptr && lane == 0) {
+    unsigned long long *o = stamps + (long)blockIdx.x * 8;
+    o[0] = ts_begin, o[1] = ts_term, o[2] = ts_bwd, o[3] = ts_root;
+    o[4] = ts_end, o[5] = acc_bwait, o[6] = acc_fwait;
+    o[7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 } // namespace sipamd

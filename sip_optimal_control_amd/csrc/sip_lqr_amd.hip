@@ -16,44 +16,77 @@ struct sip_lqr_plan {
   int64_t batch;
   int T, n, m, device;
   const char *kernel_name;
+  int ws_slot; // scalars of workspace per node
   // fused factor+solve launcher
   hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
                           void *, void *, int32_t *, void *, hipStream_t);
 };
 
+#ifdef SIP_LQR_STAMPS
+// Diagnostic build: device buffer of 8 x u64 per wave, set by the tool.
+static unsigned long long *g_stamps = nullptr;
+extern "C" void sip_lqr_debug_set_stamps(void *p) {
+  g_stamps = (unsigned long long *)p;
+}
+#define SIP_STAMP_PASS , g_stamps
+#else
+#define SIP_STAMP_PASS
+#endif
+
 namespace {
 
-template <int N, int M>
+template <int N, int M, bool STAGED, bool WPACK>
 hipError_t launch_qw16(const sip_lqr_plan *pl, const void *mats,
                        const void *vecs, void *sol, void *gains,
                        int32_t *status, void *ws, hipStream_t stream) {
+  using Cfg = sipamd::StagedCfg<N, M, WPACK>;
   const long batch = pl->batch;
   const unsigned blocks = (unsigned)((batch + 3) / 4);
-  hipLaunchKernelGGL((sipamd::chain_factor_solve_qw16<N, M>), dim3(blocks),
-                     dim3(64), 0, stream, (const double *)mats,
+  const unsigned lds = STAGED ? Cfg::LDS_BYTES : 0;
+  if (STAGED) {
+    // LDS-DMA moves 16-byte pieces: every base must be 16-byte aligned.
+    const uintptr_t bits = (uintptr_t)mats | (uintptr_t)vecs | (uintptr_t)gains |
+                           (uintptr_t)ws;
+    if (bits & 15)
+      return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL((sipamd::chain_factor_solve_qw16<N, M, STAGED, WPACK>),
+                     dim3(blocks), dim3(64), lds, stream, (const double *)mats,
                      (const double *)vecs, (double *)sol, (double *)gains,
-                     (double *)ws, (int *)status, batch, pl->T);
+                     (double *)ws, (int *)status, batch, pl->T SIP_STAMP_PASS);
   return hipGetLastError();
 }
 
 struct KernelEntry {
   int dtype, n, m;
   const char *name;
+  int ws_slot;
   hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
                           void *, void *, int32_t *, void *, hipStream_t);
 };
 
-#define QW16(N, M)                                                             \
-  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ">/f64",           \
-    &launch_qw16<N, M> }
+// direct: every lane loads its columns from global memory (any N <= 15)
+#define QW16_DIRECT(N, M)                                                      \
+  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",direct>/f64",    \
+    sipamd::StagedCfg<N, M, false>::WSN, &launch_qw16<N, M, false, false> }
+// staged: LDS-DMA double buffering + packed symmetric W spill (N, M even)
+#define QW16_STAGED(N, M)                                                      \
+  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",staged>/f64",    \
+    sipamd::StagedCfg<N, M, true>::WSN, &launch_qw16<N, M, true, true> }
 
+// First match wins; SIP_LQR_VARIANT=direct|staged (tests, A/B timing) narrows
+// the search to kernels whose name carries that tag.
 const KernelEntry kKernels[] = {
-    QW16(12, 4), QW16(4, 2), QW16(1, 1), QW16(2, 1), QW16(3, 2), QW16(8, 3),
+    QW16_STAGED(12, 4), QW16_STAGED(4, 2), QW16_DIRECT(12, 4),
+    QW16_DIRECT(4, 2),  QW16_DIRECT(1, 1), QW16_DIRECT(2, 1),
+    QW16_DIRECT(3, 2),  QW16_DIRECT(8, 3),
 };
 
 const KernelEntry *find_kernel(int dtype, int n, int m) {
+  const char *want = std::getenv("SIP_LQR_VARIANT");
   for (const auto &k : kKernels)
-    if (k.dtype == dtype && k.n == n && k.m == m)
+    if (k.dtype == dtype && k.n == n && k.m == m &&
+        (want == nullptr || want[0] == 0 || std::strstr(k.name, want)))
       return &k;
   return nullptr;
 }
@@ -87,6 +120,7 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
   p->m = m;
   p->device = device;
   p->kernel_name = k->name;
+  p->ws_slot = k->ws_slot;
   p->launch_fs = k->launch_fs;
   *plan = p;
   return SIP_LQR_OK;
@@ -122,8 +156,8 @@ size_t sip_lqr_status_bytes(const sip_lqr_plan *p) {
   return (size_t)p->batch * sizeof(int32_t);
 }
 size_t sip_lqr_workspace_bytes(const sip_lqr_plan *p) {
-  const size_t n = p->n, T = p->T;
-  return (size_t)p->batch * (T + 1) * (n * n + n) * scalar_size(p);
+  return (size_t)p->batch * ((size_t)p->T + 1) * (size_t)p->ws_slot *
+         scalar_size(p);
 }
 
 } // extern "C"
