@@ -101,6 +101,7 @@ def main():
     import torch
     import torch.distributed as dist
     from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
+    from sip_optimal_control_amd.sharding import GainsAllGather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,38 +125,29 @@ def main():
     mats, vecs = synthetic.make_chain_batch(shape, batch, seed=1234 + rank, device=device, dtype=dtype)
     solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device=device)
     sol = solver.empty_sol()
-    gains = [solver.empty_gains(), solver.empty_gains()]
     gather = world > 1 and not args.no_gather
     if gather:
-        all_gains = [torch.empty(world * batch, shape.gains_len, dtype=dtype, device=device)
-                     for _ in range(2)]
-        comm_stream = torch.cuda.Stream(device)
-        gathered = [None, None]
+        ag = GainsAllGather(batch, shape.gains_len, dtype, device)
+    else:
+        gains = [solver.empty_gains(), solver.empty_gains()]
 
     compute = torch.cuda.current_stream(device)
     kernel_events = []
 
     def step(i, timed):
-        b = i & 1
-        if gather and gathered[b] is not None:
-            compute.wait_event(gathered[b])  # gains[b] is still being read by the gather of step i-2
+        # gains are double-buffered; with the gather on, buffer i%2 is only
+        # rewritten once the all-gather of sweep i-2 has drained it
+        out_gains = ag.acquire(i) if gather else gains[i & 1]
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(compute)
-        solver.factor_solve(mats, vecs, sol, gains[b])
+        solver.factor_solve(mats, vecs, sol, out_gains)
         if timed:
             e1.record(compute)
             kernel_events.append((e0, e1))
         if gather:
-            done = torch.cuda.Event()
-            done.record(compute)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(done)
-                dist.all_gather_into_tensor(all_gains[b], gains[b])
-                g = torch.cuda.Event()
-                g.record(comm_stream)
-            gathered[b] = g
+            ag.launch(i)  # RCCL all-gather on the side stream, overlaps sweep i+1
 
     def fence():
         if world > 1:
@@ -169,9 +161,7 @@ def main():
     for i in range(args.steps):
         step(i, True)
     if gather:
-        for g in gathered:
-            if g is not None:
-                compute.wait_event(g)
+        ag.finish()
     torch.cuda.synchronize(device)
     elapsed_local = time.perf_counter() - t0
     fence()
