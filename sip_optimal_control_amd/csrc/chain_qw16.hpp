@@ -68,44 +68,60 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return __builtin_fma(y * e, t, y);
 }
 
-// In-place lower Cholesky of the S x S symmetric matrix held one column per
-// lane (lanes c < S).  On exit lane j holds L(i,j) in A[i], i >= j; rinv[k] =
-// 1 / L(k,k) replicated in every lane.  Returns true iff a pivot was <= 0.
+// 1/d: v_rcp_f64 seed + one third-order Newton step (full fp64).
+__device__ __forceinline__ double rcp_nr(double d) {
+  const double y = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, y, 1.0);
+  const double t = __builtin_fma(e, e, e);
+  return __builtin_fma(y, t, y);
+}
+
+// In-place square-root-free Cholesky (A = Lt D^-1 Lt^T) of the S x S symmetric
+// matrix held one column per lane (lanes c < S).  On exit lane j holds
+// Lt(i,j) = L(i,j) * L(j,j) in A[i], i >= j (so A[j] of lane j is the pivot
+// d_j = L(j,j)^2 of Eigen's LLT) and dinv[k] = 1 / d_k replicated in every
+// lane.  Pivots are those of the Cholesky factorisation, so "a pivot <= 0"
+// (Eigen: NumericalIssue) is detected identically.  Returns true on failure.
+//
+// Step k broadcasts the *unscaled* pivot column (last written by the previous
+// step's update, many instructions ago), so no DPP wait state is needed.
 template <int S>
-__device__ __forceinline__ bool chol_lower_dpp(double (&A)[S], double (&rinv)[S],
-                                               const int c) {
+__device__ __forceinline__ bool chol_ldl_dpp(double (&A)[S], double (&dinv)[S],
+                                             const int c) {
   bool fail = false;
   sfor<0, S>([&](auto kk) {
     constexpr int k = decltype(kk)::value;
     const double d = bcast<k>(A[k]);
     fail |= (d <= 0.0);
-    const double y = rsqrt_nr(d);
-    rinv[k] = y;
-    const double lk = A[k] * y; // lane j > k: L(j,k) by symmetry
-    const double upd = (c > k && c < S) ? lk : 0.0;
-    const double ysel = (c == k) ? y : 1.0;
-    sfor<k, S>([&](auto ii) { A[decltype(ii)::value] *= ysel; });
-    // A(i,j) -= L(i,k) L(j,k), i > k, lanes j > k
-    rank1<S - k - 1, k, true, true>(A + k + 1, A + k + 1, upd);
+    const double y2 = rcp_nr(d);
+    dinv[k] = y2;
+    // lane j > k: Lt(j,k) / d_k (by symmetry its own A[k] is Lt(j,k))
+    const double upd = (c > k && c < S) ? A[k] * y2 : 0.0;
+    // A(i,j) -= Lt(i,k) Lt(j,k) / d_k, i > k, lanes j > k
+    rank1<S - k - 1, k, true, false>(A + k + 1, A + k + 1, upd);
   });
   return fail;
 }
 
-// X <- (L L^T)^{-1} X for X held one column per lane (any lane of the row may
-// carry a right-hand side), L / rinv as produced by chol_lower_dpp.
+// X <- (Lt D^-1 Lt^T)^{-1} X for X held one column per lane (any lane of the
+// row may carry a right-hand side); Lt / dinv from chol_ldl_dpp.
+//   forward :  w_j = (x_j - sum_{i<j} Lt(j,i) w_i) / d_j
+//   backward:  x_j = w_j - (sum_{i>j} Lt(i,j) x_i) / d_j
 template <int S>
-__device__ __forceinline__ void chol_solve_dpp(const double (&L)[S],
-                                               const double (&rinv)[S],
-                                               double (&X)[S]) {
+__device__ __forceinline__ void ldl_solve_dpp(const double (&Lt)[S],
+                                              const double (&dinv)[S],
+                                              double (&X)[S]) {
   sfor<0, S>([&](auto jj) {
     constexpr int j = decltype(jj)::value;
-    X[j] *= rinv[j];
-    rank1<S - j - 1, j, true, true>(X + j + 1, L + j + 1, X[j]);
+    X[j] *= dinv[j];
+    rank1<S - j - 1, j, true, (j == 0)>(X + j + 1, Lt + j + 1, X[j]);
   });
+  double acc[S];
+  sfor<0, S>([&](auto jj) { acc[decltype(jj)::value] = 0.0; });
   sfor_down<S - 1, -1>([&](auto jj) {
     constexpr int j = decltype(jj)::value;
-    X[j] *= rinv[j];
-    spread<j, true, true>(X, L[j], X[j]); // X[i] -= L(j,i) X[j], i < j
+    X[j] = __builtin_fma(-dinv[j], acc[j], X[j]);
+    spread<j, false, false>(acc, Lt[j], X[j]); // acc[i] += Lt(j,i) x_j, i < j
   });
 }
 
@@ -135,10 +151,10 @@ __device__ __forceinline__ bool node_factor(const double (&V)[N], const double d
     constexpr int r = decltype(ii)::value;
     A[r] = __builtin_fma(S[r], V[r], E[r]); // I + D^1/2 V D^1/2, lqr.cpp:497-503
   });
-  const bool fail = chol_lower_dpp<N>(A, rinv, c);
+  const bool fail = chol_ldl_dpp<N>(A, rinv, c); // LLT of lqr.cpp:505
   double X[N];
   sfor<0, N>([&](auto ii) { X[decltype(ii)::value] = E[decltype(ii)::value]; });
-  chol_solve_dpp<N>(A, rinv, X); // F^{-1}, lqr.cpp:516-519
+  ldl_solve_dpp<N>(A, rinv, X); // F^{-1}, lqr.cpp:516-519
   sfor<0, N>([&](auto ii) { S[decltype(ii)::value] = 0.0; });
   spread<N, false, true>(S, sdi, sdi);
   sfor<0, N>([&](auto ii) {
@@ -228,9 +244,18 @@ struct StagedCfg {
   using FC = StageDma<N / 2>;
   static constexpr int F_BYTES =
       FA::BYTES + FG::BYTES + FW::BYTES + 2 * FC::BYTES;
-  static constexpr int NBUF = 2;
-  static constexpr int LDS_BYTES =
-      NBUF * (B_BYTES > F_BYTES ? B_BYTES : F_BYTES);
+  // LDS-DMA instructions per forward stage: the count the rollout's
+  // `s_waitcnt vmcnt(F_GLDS)` relies on.
+  static constexpr int F_GLDS =
+      FA::INSTR + FG::INSTR + FW::INSTR + 2 * FC::INSTR;
+  static constexpr int B_NBUF = 2; // backward: one stage ahead
+#ifndef SIP_LQR_FNBUF
+#define SIP_LQR_FNBUF 3
+#endif
+  static constexpr int F_NBUF = SIP_LQR_FNBUF; // forward: F_NBUF-1 stages ahead
+  static constexpr int LDS_BYTES = B_NBUF * B_BYTES > F_NBUF * F_BYTES
+                                       ? B_NBUF * B_BYTES
+                                       : F_NBUF * F_BYTES;
   static constexpr bool OK = (N % 2 == 0) && (M % 2 == 0);
 };
 
@@ -352,16 +377,16 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
                            const double(&Rcol)[M], double(&Vn)[N]) {
     // [F | g - v_c] = W [A | t]   (lqr.cpp:703 and :780-781)
     double F[N];
-    sfor<0, N>([&](auto ii) { F[decltype(ii)::value] = 0.0; });
-    sfor<0, N>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      const double a = isV ? t[k] : Acol[k];
-      rank1<N, k, false, true>(F, W, a);
-    });
     sfor<0, N>([&](auto ii) {
       constexpr int r = decltype(ii)::value;
-      F[r] += isV ? vch[r] : 0.0; // vector lane: g
+      F[r] = isV ? vch[r] : 0.0; // vector lane accumulates g = v_c + W t
     });
+    double Aaug[N];
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      Aaug[k] = isV ? t[k] : Acol[k];
+    });
+    rank1x<N, N, true>(F, W, Aaug);
     if (valid && isV) {
       double *gn = pw + (long)(i + 1) * WSN + WG;
       sfor<0, N>(
@@ -371,17 +396,11 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     // H_child = B^T W (lqr.cpp:692); G = R + H_child B (lqr.cpp:693-694)
     double Hc[M], G[M], rinvG[M];
     sfor<0, M>([&](auto jj) { Hc[decltype(jj)::value] = 0.0; });
-    sfor<0, N>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      spread<M, false, true>(Hc, Bcol[k], W[k]);
-    });
+    spreadx<M, N, false>(Hc, Bcol, W);
     sfor<0, M>(
         [&](auto jj) { G[decltype(jj)::value] = Rcol[decltype(jj)::value]; });
-    sfor<0, N>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      rank1<M, k, false, true>(G, Hc, Bcol[k]);
-    });
-    const bool gfail = chol_lower_dpp<M>(G, rinvG, c); // lqr.cpp:696-701
+    rank1x<M, N, true>(G, Hc, Bcol);
+    const bool gfail = chol_ldl_dpp<M>(G, rinvG, c); // lqr.cpp:696-701
     if (stat == 0 && gfail)
       stat = 3; // G_FACTORIZATION_FAILURE
 
@@ -389,14 +408,11 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     double H[M], K[M];
     sfor<0, M>(
         [&](auto jj) { H[decltype(jj)::value] = MT[decltype(jj)::value]; });
-    sfor<0, N>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      spread<M, false, true>(H, Bcol[k], F[k]);
-    });
+    spreadx<M, N, false>(H, Bcol, F);
     // [K | k] = -G^{-1} [H | h]   (lqr.cpp:707-713, :785-791)
     sfor<0, M>(
         [&](auto jj) { K[decltype(jj)::value] = H[decltype(jj)::value]; });
-    chol_solve_dpp<M>(G, rinvG, K);
+    ldl_solve_dpp<M>(G, rinvG, K);
     sfor<0, M>(
         [&](auto jj) { K[decltype(jj)::value] = -K[decltype(jj)::value]; });
     if (valid && c <= N) {
@@ -406,14 +422,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     }
 
     // [V | v] = [Q | q] + A^T [F | g] + K^T [H | h]  (lqr.cpp:715-719,:793-794)
-    sfor<0, N>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      spread<N, false, true>(Vn, Acol[k], F[k]);
-    });
-    sfor<0, M>([&](auto jj) {
-      constexpr int j = decltype(jj)::value;
-      spread<N, false, true>(Vn, K[j], H[j]);
-    });
+    spreadx<N, N, false>(Vn, Acol, F);
+    spreadx<N, M, true>(Vn, K, H);
     sfor<0, N>(
         [&](auto ii) { V[decltype(ii)::value] = Vn[decltype(ii)::value]; });
   };
@@ -494,10 +504,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   {
     double F[N];
     sfor<0, N>([&](auto ii) { F[decltype(ii)::value] = 0.0; });
-    sfor<0, N>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      rank1<N, k, false, true>(F, W, t[k]);
-    });
+    rank1x<N, N, true>(F, W, t);
     if (valid && isV) {
       double *gn = pw + WG;
       sfor<0, N>([&](auto ii) {
@@ -555,6 +562,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   if constexpr (STAGED) {
     if (T > 0)
       issue_forward(0, lds);
+    if (C::F_NBUF == 3 && T > 1)
+      issue_forward(1, lds + C::F_BYTES);
   }
 
   double x, y;
@@ -569,6 +578,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       ps[N + c] = y;
     }
   }
+  int fbuf = 0; // LDS buffer of stage i = i % F_NBUF
   for (int i = 0; i < T; ++i) {
     double KT[N], Arow[N], Brow[M], Wc[N];
     double kk0, gg, cc, dd;
@@ -590,8 +600,15 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     };
     SIP_STAMP(ts_a);
     if constexpr (STAGED) {
-      lds_char *buf = lds + (i & 1) * C::F_BYTES;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_char *buf = lds + (fbuf * C::F_BYTES);
+      // Stage i+1's LDS-DMA (F_GLDS instructions, the youngest vector-memory
+      // operations of this wave: issued after the previous iteration's
+      // stores) may stay in flight; everything older -- stage i -- has landed.
+      static_assert(C::F_GLDS < 64, "vmcnt is 6 bits");
+      if (C::F_NBUF == 3 && i + 1 < T)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::F_GLDS) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SIP_STAMP(ts_b);
       acc_fwait += ts_b - ts_a;
       lds_char *b1 = buf + C::FA::BYTES, *b2 = b1 + C::FG::BYTES,
@@ -602,8 +619,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
                  (lds_cdouble *)(b3 + rr * (N * 8)),
                  (lds_cdouble *)(b4 + rr * (N * 8)));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (i + 1 < T)
-        issue_forward(i + 1, lds + ((i + 1) & 1) * C::F_BYTES);
+      if (C::F_NBUF == 2 && i + 1 < T) // one stage ahead, behind this stage's arithmetic
+        issue_forward(i + 1, lds + (fbuf ^ 1) * C::F_BYTES);
     } else {
       read_stage(pm + (long)i * STG + L::NODE, pg + (long)i * L::GAIN,
                  pw + (long)(i + 1) * WSN, pv + (long)(i + 1) * VSTG + N,
@@ -633,6 +650,14 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
         si[VSTG + c] = x;
         si[VSTG + N + c] = y;
       }
+    }
+    if constexpr (STAGED) {
+      // Keep the stores above older than the DMA below (see the vmcnt count).
+      asm volatile("" ::: "memory");
+      const int nbuf = fbuf >= 1 ? fbuf - 1 : C::F_NBUF - 1; // (i + 2) % 3
+      if (C::F_NBUF == 3 && i + 2 < T)
+        issue_forward(i + 2, lds + nbuf * C::F_BYTES);
+      fbuf = fbuf + 1 == C::F_NBUF ? 0 : fbuf + 1;
     }
   }
 #ifdef SIP_LQR_STAMPS

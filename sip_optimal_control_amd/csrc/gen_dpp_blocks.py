@@ -84,6 +84,33 @@ def emit_dotv(out, R):
     out.append("}\n")
 
 
+def emit_x(out, kind, R, K):
+    """Whole products in one asm statement (fewer statement boundaries for the
+    compiler to pad): rank1x: C[i] += A[i]@lane k * B[k]; spreadx: C[i] += A[k]@lane i * B[k]."""
+    outs = ", ".join(f'"+v"(C[{i}])' for i in range(R))
+    na = R if kind == "rank1x" else K
+    ins = ", ".join(f'"v"(A[{i}])' for i in range(na)) + ", " + ", ".join(f'"v"(B[{k}])' for k in range(K))
+    out.append(f"template <bool WAIT>\n"
+               f"__device__ __forceinline__ void {kind}_{R}_{K}(double *C, const double *A, const double *B) {{")
+    for wait in (False, True):
+        lines = ["s_nop 1"] if wait else []
+        for k in range(K):
+            for i in range(R):
+                if kind == "rank1x":
+                    lines.append(f"v_fmac_f64_dpp %{i}, %{R + i}, %{R + na + k} row_newbcast:{k} "
+                                 "row_mask:0xf bank_mask:0xf")
+                else:
+                    lines.append(f"v_fmac_f64_dpp %{i}, %{R + k}, %{R + na + k} row_newbcast:{i} "
+                                 "row_mask:0xf bank_mask:0xf")
+        s = "\\n\\t".join(lines)
+        out.append(f"  if constexpr (WAIT == {str(wait).lower()})\n"
+                   f'    asm volatile("{s}"\n        : {outs}\n        : {ins});')
+    out.append("}\n")
+
+
+XSIZES = [1, 2, 3, 4, 6, 8, 12]
+
+
 def main(path):
     out = [
         "// GENERATED by gen_dpp_blocks.py -- do not edit.",
@@ -98,7 +125,21 @@ def main(path):
         emit_rank1(out, R)
         emit_spread(out, R)
         emit_dotv(out, R)
+    for R in XSIZES:
+        for K in XSIZES:
+            emit_x(out, "rank1x", R, K)
+            emit_x(out, "spreadx", R, K)
     out.append("} // namespace dppgen\n")
+    for kind in ("rank1x", "spreadx"):
+        out.append(f"template <int R, int K, bool WAIT>\n"
+                   f"__device__ __forceinline__ void {kind}(double *C, const double *A, const double *B) {{")
+        conds = " || ".join(f"V == {v}" for v in XSIZES)
+        out.append("  constexpr auto ok = [](int V) { return %s; };" % conds)
+        out.append("  static_assert(ok(R) && ok(K), \"add the size to XSIZES in gen_dpp_blocks.py\");")
+        for R in XSIZES:
+            for K in XSIZES:
+                out.append(f"  if constexpr (R == {R} && K == {K}) dppgen::{kind}_{R}_{K}<WAIT>(C, A, B);")
+        out.append("}\n")
     # dispatchers on R
     out.append("template <int R, int K, bool NEG, bool WAIT>\n"
                "__device__ __forceinline__ void rank1(double *C, const double *A, double b) {")

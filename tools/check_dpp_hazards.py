@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Static check of the gfx9 DPP read-after-VALU-write hazard in a compiled kernel.
+
+hipcc pads the hazards of the instructions it emits but nothing inside an
+`asm` string, and our fused `v_fmac_f64_dpp ... row_newbcast` blocks live in
+asm strings.  The hardware needs 2 wait states between a VALU write of a VGPR
+and a DPP instruction reading it as its (lane-permuted) src0, and 5 between a
+VALU write of EXEC and any DPP instruction.  This script walks the `.s` of the
+device code (hipcc -save-temps) and reports every DPP read whose source
+register was written by a VALU instruction fewer than 2 wait states earlier on
+ANY path (fall-through or branch), and every v_cmpx within 5 wait states of a
+DPP instruction.
+
+usage: check_dpp_hazards.py file.s [kernel-name-substring ...]; exit code 1 on a hazard.
+"""
+import re
+import sys
+
+VALU_PREFIX = ("v_",)
+NOT_VALU_WRITERS = ("v_cmp_", "v_cmpx_", "v_readlane", "v_readfirstlane", "v_nop")
+
+
+def regs(token):
+    token = token.strip().lstrip("-|").rstrip("|,")
+    m = re.match(r"^v\[(\d+):(\d+)\]$", token)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"^v(\d+)$", token)
+    if m:
+        return {int(m.group(1))}
+    return set()
+
+
+def parse_kernel(lines):
+    """-> list of items: ('label', name) | ('ins', mnemonic, operands[list], text)"""
+    items = []
+    for raw in lines:
+        line = raw.split(";")[0].rstrip()
+        if not line.strip():
+            continue
+        m = re.match(r"^(\.?[A-Za-z_][\w.$]*):", line)
+        if m and not line.startswith("\t"):
+            items.append(("label", m.group(1)))
+            continue
+        s = line.strip()
+        if s.startswith("."):
+            continue
+        parts = s.split(None, 1)
+        mnem = parts[0]
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        items.append(("ins", mnem, ops, s))
+    return items
+
+
+def wait_states(item):
+    if item[1] == "s_nop":
+        return int(item[2][0], 0) + 1
+    return 1
+
+
+def valu_written(item):
+    mnem, ops = item[1], item[2]
+    if not mnem.startswith(VALU_PREFIX) or mnem.startswith(NOT_VALU_WRITERS) or not ops:
+        return set()
+    return regs(ops[0])
+
+
+def dpp_source(item):
+    mnem, ops, text = item[1], item[2], item[3]
+    if "_dpp" not in mnem and "row_newbcast" not in text and "quad_perm" not in text \
+            and "row_shr" not in text and "row_shl" not in text and "row_ror" not in text \
+            and "row_bcast" not in text and "row_mirror" not in text and "wave_" not in text:
+        return None
+    if len(ops) < 2:
+        return set()
+    src0 = ops[1].split()[0]
+    return regs(src0)
+
+
+def check(items, name):
+    # control-flow: index of labels, predecessors by branch
+    label_at = {it[1]: i for i, it in enumerate(items) if it[0] == "label"}
+    branch_preds = {}
+    for i, it in enumerate(items):
+        if it[0] == "ins" and (it[1].startswith("s_cbranch") or it[1] == "s_branch"):
+            tgt = it[2][0] if it[2] else None
+            if tgt in label_at:
+                branch_preds.setdefault(label_at[tgt], []).append(i)
+
+    def preceding(i, budget):
+        """Yield (instruction, wait states between it and instruction i) along every
+        backward path (fall-through and branches), up to `budget` wait states."""
+        stack = [(i - 1, 0)]
+        seen = set()
+        while stack:
+            j, ws = stack.pop()
+            while j >= 0 and ws < budget and (j, ws) not in seen:
+                seen.add((j, ws))
+                it = items[j]
+                if it[0] == "label":
+                    for b in branch_preds.get(j, []):
+                        stack.append((b, ws))
+                    k = j - 1
+                    while k >= 0 and items[k][0] == "label":
+                        k -= 1
+                    if k >= 0 and items[k][1] in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                        break  # no fall-through into this label
+                    j -= 1
+                    continue
+                yield it, ws
+                ws += wait_states(it)
+                j -= 1
+
+    problems = []
+    for i, it in enumerate(items):
+        if it[0] != "ins":
+            continue
+        src = dpp_source(it)
+        if src is None:
+            continue
+        for prev, ws in preceding(i, 5):
+            if ws < 2 and (valu_written(prev) & src):
+                problems.append((name, prev[3], it[3], ws, "VALU write -> DPP read needs 2 wait states"))
+            if prev[1].startswith("v_cmpx") and ws < 5:
+                problems.append((name, prev[3], it[3], ws, "VALU EXEC write -> DPP needs 5 wait states"))
+    return problems
+
+
+def main():
+    path = sys.argv[1]
+    wanted = sys.argv[2:]
+    lines = open(path).read().split("\n")
+    kernels = {}
+    cur = None
+    for ln in lines:
+        m = re.match(r"^(_Z\w+|[A-Za-z_]\w*):\s*;?\s*@", ln)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+            continue
+        if cur is not None:
+            kernels[cur].append(ln)
+            if ln.strip().startswith("s_endpgm"):
+                cur = None
+    total = 0
+    checked = 0
+    for name, body in kernels.items():
+        if wanted and not any(w in name for w in wanted):
+            continue
+        items = parse_kernel(body)
+        ndpp = sum(1 for it in items if it[0] == "ins" and dpp_source(it) is not None)
+        probs = check(items, name)
+        checked += 1
+        print(f"{name}: {ndpp} DPP instructions, {len(probs)} hazard(s)")
+        for p in probs[:20]:
+            print(f"   [{p[4]}; {p[3]} wait state(s)]\n      writer: {p[1]}\n      reader: {p[2]}")
+        total += len(probs)
+    if checked == 0:
+        print("no kernel matched")
+        return 2
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
