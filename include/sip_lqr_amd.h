@@ -147,6 +147,76 @@ int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats,
                   const void *d_vecs, void *d_sol, void *d_gains,
                   void *d_workspace, void *stream);
 
+/* ------------------------------------------------------------------------
+ * General trees / per-node dimensions (the full Topology + Dimensions model
+ * of lqr.hpp:5-64): the path behind the drop-in C++ `LQR` adapter
+ * (include/sip_optimal_control_amd/lqr_dropin.hpp).  `batch` instances of ONE
+ * topology and dimension table, each with its own data; fp64; state and
+ * control dimensions >= 0 (0 allowed, tests/variable_dimensions_test.cpp:
+ * 316-336).
+ *
+ * Arenas (scalars = double, offsets from sip_lqr_tree_offset()):
+ *   input  [batch][ node blocks: Q (n*n) | q (n) | c (n) | delta (n) ;
+ *                   edge blocks: A (nc*np) | B (nc*m) | M (np*m) | R (m*m) | r (m) ]
+ *   work   [batch][ edge blocks: W (max_n^2) | K (m*np) | G_factor (m*m) | k (m) ;
+ *                   node blocks: V (n*n) | F_factor (n*n) | sqrt_delta (n) |
+ *                                sqrt_delta_inv (n) | v (n) ; scratch ]
+ *                  -- the fields of LQR::Workspace (lqr.hpp:110-127), same
+ *                     meaning, so their consumers (helpers.cpp:521-665) can be
+ *                     served from a copy of it
+ *   output [batch][ node blocks: x (n) | y (n) ; edge blocks: u (m) ]
+ * ------------------------------------------------------------------------ */
+typedef struct sip_lqr_tree_plan sip_lqr_tree_plan;
+
+/* Host-side topology compilation.  Replaces: compile_topology_data
+ * (lqr.cpp:563-631): validates the edge list, builds the CSR children lists
+ * (stable in edge index), DFS preorder (lowest edge index first) and the
+ * reversed-preorder "postorder".  Output arrays are caller-owned with the sizes
+ * of LQR::Workspace (lqr.hpp:129-135): child_offsets[N+1], child_edges[E],
+ * edge_parents_out[E], edge_children_out[E], preorder[N], postorder[N],
+ * node_marks[N].  Returns a FactorStatus (SUCCESS or INVALID_TOPOLOGY). */
+int sip_lqr_compile_topology(int num_edges, int root, const int *edge_parents,
+                             const int *edge_children, int *child_offsets,
+                             int *child_edges, int *edge_parents_out,
+                             int *edge_children_out, int *preorder,
+                             int *postorder, int *node_marks);
+
+/* Replaces: LQR::LQR + compile_topology (lqr.cpp:635-643) for `batch`
+ * instances.  An invalid topology still yields a plan; its status is latched
+ * (lqr.cpp:646-648) and returned by every sip_lqr_tree_factor(). */
+int sip_lqr_tree_plan_create(int64_t batch, int num_edges, int root,
+                             const int *edge_parents, const int *edge_children,
+                             const int *state_dims, const int *control_dims,
+                             int device, sip_lqr_tree_plan **plan);
+void sip_lqr_tree_plan_destroy(sip_lqr_tree_plan *plan);
+int sip_lqr_tree_topology_status(const sip_lqr_tree_plan *plan);
+/* Compiled traversal (host copies, valid when the topology is valid):
+ * which = 0 child_offsets[N+1], 1 child_edges[E], 2 preorder[N], 3 postorder[N] */
+const int *sip_lqr_tree_topology_array(const sip_lqr_tree_plan *plan, int which);
+
+/* Per-problem arena lengths in doubles. */
+size_t sip_lqr_tree_input_len(const sip_lqr_tree_plan *plan);
+size_t sip_lqr_tree_work_len(const sip_lqr_tree_plan *plan);
+size_t sip_lqr_tree_output_len(const sip_lqr_tree_plan *plan);
+/* Offset (in doubles, inside one problem) of a block: arena 0 = input,
+ * 1 = work, 2 = output; kind 0 = node block, 1 = edge block; index = node or
+ * edge id.  Returns (size_t)-1 on a bad argument. */
+size_t sip_lqr_tree_offset(const sip_lqr_tree_plan *plan, int arena, int kind,
+                           int index);
+
+/* Replaces: LQR::factor_with_status() (lqr.cpp:645-731) for every instance:
+ * reads Q, M, R, A, B, delta from d_input, writes the factor state to d_work
+ * and FactorStatus codes to d_status[batch].  Asynchronous on `stream`. */
+int sip_lqr_tree_factor(const sip_lqr_tree_plan *plan, const double *d_input,
+                        double *d_work, int32_t *d_status, void *stream);
+/* Replaces: LQR::solve(Output&) (lqr.cpp:735-871): reads q, r, c (and A, B,
+ * delta) from d_input and the factor state from d_work, writes x, u, y to
+ * d_output and k, v to d_work.  Instances whose d_status != SUCCESS are
+ * skipped.  May be called repeatedly after one factor. */
+int sip_lqr_tree_solve(const sip_lqr_tree_plan *plan, const double *d_input,
+                       double *d_work, double *d_output,
+                       const int32_t *d_status, void *stream);
+
 /* Name of the kernel variant the plan dispatches to (static string). */
 const char *sip_lqr_kernel_name(const sip_lqr_plan *plan);
 

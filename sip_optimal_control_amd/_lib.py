@@ -41,6 +41,18 @@ _SIGNATURES = {
     "sip_lqr_factor_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sip_lqr_factor": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "sip_lqr_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "sip_lqr_compile_topology": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [_P] * 9),
+    "sip_lqr_tree_plan_create": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P,
+                                                ctypes.c_int, _PP]),
+    "sip_lqr_tree_plan_destroy": (None, [_P]),
+    "sip_lqr_tree_topology_status": (ctypes.c_int, [_P]),
+    "sip_lqr_tree_topology_array": (ctypes.POINTER(ctypes.c_int), [_P, ctypes.c_int]),
+    "sip_lqr_tree_input_len": (ctypes.c_size_t, [_P]),
+    "sip_lqr_tree_work_len": (ctypes.c_size_t, [_P]),
+    "sip_lqr_tree_output_len": (ctypes.c_size_t, [_P]),
+    "sip_lqr_tree_offset": (ctypes.c_size_t, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sip_lqr_tree_factor": (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    "sip_lqr_tree_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "sip_lqr_kernel_name": (ctypes.c_char_p, [_P]),
     "sip_lqr_version": (ctypes.c_char_p, []),
 }

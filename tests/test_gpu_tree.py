@@ -1,0 +1,157 @@
+"""General tree / variable-dimension HIP path (through the C ABI) against the
+reference's own tree fixtures, the oracle and the dense-KKT golden vectors.
+Tolerance: 1e-10 relative l2 per block (the reference's own dense check,
+tests/lqr_test.cpp:995-1010) and KKT residual < 1e-12."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import reference_problems as rp
+from oracle import dense_kkt
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _solver(prob, batch=1, **kw):
+    from sip_optimal_control_amd.tree import BatchedTreeLQR
+    return BatchedTreeLQR(prob["parents"], prob["children"], prob["state_dims"], prob["control_dims"],
+                          batch=batch, **kw)
+
+
+def _status(prob):
+    s = _solver(prob)
+    if s.topology_status == 0:
+        s.pack([prob["blocks"]])
+    st = s.factor()
+    torch.cuda.synchronize()
+    return int(st[0])
+
+
+def test_status_kats():
+    """lqr_test.cpp:188-227: SUCCESS, INVALID_DELTA, F and G factorization failures."""
+    assert _status(rp.default_chain(2, 1, 2)) == 0
+    p = rp.default_chain(2, 1, 2)
+    p["blocks"]["delta"][2][0] = 0.0
+    assert _status(p) == 1
+    p = rp.default_chain(1, 1, 1)
+    p["blocks"]["Q"][1][0, 0] = -2.0
+    assert _status(p) == 2
+    p = rp.default_chain(1, 1, 1)
+    p["blocks"]["Q"][1][0, 0] = 0.0
+    p["blocks"]["R"][0][0, 0] = -1.0
+    assert _status(p) == 3
+
+
+def test_invalid_topology_is_latched():
+    """lqr_test.cpp:452-464, 955-980: INVALID_TOPOLOGY from every factor call."""
+    p = rp.branch_tree()
+    p["children"][1] = 1
+    s = _solver(p)
+    assert s.topology_status == 4
+    for _ in range(2):
+        st = s.factor()
+        torch.cuda.synchronize()
+        assert int(st[0]) == 4
+
+
+@pytest.mark.parametrize("name", ["nonuniform_diagonal_delta", "branch_tree",
+                                  "variable_dimension_branch", "five_node_variable_tree"])
+def test_reference_fixtures(oracle_lib, name):
+    builders = {"nonuniform_diagonal_delta": rp.nonuniform_diagonal_delta, "branch_tree": rp.branch_tree,
+                "variable_dimension_branch": rp.variable_dimension_branch,
+                "five_node_variable_tree": rp.five_node_variable_tree_eigen}
+    prob = builders[name]()
+    s = _solver(prob)
+    s.pack([prob["blocks"]])
+    assert int(s.factor()[0]) == 0
+    assert int(s.factor()[0]) == 0          # factor twice, solve twice (lqr_test.cpp:431-450)
+    s.solve()
+    s.solve()
+    torch.cuda.synchronize()
+    x, u, y = s.unpack_solution()
+    res = dense_kkt.residual_norm(prob["parents"], prob["children"], prob["state_dims"],
+                                  prob["control_dims"], prob["blocks"], x, u, y)
+    assert res < 1e-12
+    d = np.load(os.path.join(GOLD, f"tree_{name}.npz"))
+    for got, want in ((np.concatenate(x), d["x"]), (np.concatenate(u), d["u"]), (np.concatenate(y), d["y"])):
+        assert np.linalg.norm(got - want) <= 1e-10 * np.linalg.norm(want)
+    lqr = oracle_lib.TreeLQR(prob["parents"], prob["children"], prob["state_dims"],
+                             prob["control_dims"], prob["blocks"])
+    assert lqr.factor() == 0
+    xo, uo, yo = lqr.solve()
+    for a, b in list(zip(x, xo)) + list(zip(u, uo)) + list(zip(y, yo)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12 * max(1.0, np.abs(b).max()))
+    Ko, ko = lqr.gains()
+    Kg, kg = s.unpack_gains()
+    for a, b in list(zip(Kg, Ko)) + list(zip(kg, ko)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+    assert s.topology_arrays() == lqr.topology_arrays()
+
+
+def test_zero_dimensional_root():
+    """tests/variable_dimensions_test.cpp:316-336."""
+    rng = np.random.default_rng(5)
+    blocks = {"Q": [np.zeros((0, 0)), np.eye(2) * 1.5], "q": [np.zeros(0), rng.normal(size=2)],
+              "c": [np.zeros(0), rng.normal(size=2)], "delta": [np.zeros(0), np.array([0.5, 0.7])],
+              "M": [np.zeros((0, 1))], "R": [np.array([[1.2]])], "A": [np.zeros((2, 0))],
+              "B": [rng.normal(size=(2, 1))], "r": [rng.normal(size=1)]}
+    prob = dict(parents=[0], children=[1], state_dims=[0, 2], control_dims=[1], blocks=blocks)
+    s = _solver(prob)
+    s.pack([blocks])
+    assert int(s.factor()[0]) == 0
+    s.solve()
+    torch.cuda.synchronize()
+    x, u, y = s.unpack_solution()
+    assert dense_kkt.residual_norm([0], [1], [0, 2], [1], blocks, x, u, y) < 1e-12
+
+
+def test_random_tree_batch_matches_oracle(oracle_lib):
+    """A batch of instances of one random tree (variable dims), one of them made to fail."""
+    rng = np.random.default_rng(21)
+    N = 9
+    parents = [int(rng.integers(0, e + 1)) for e in range(N - 1)]
+    children = list(range(1, N))
+    sd = [int(rng.integers(1, 7)) for _ in range(N)]
+    cd = [int(rng.integers(1, 4)) for _ in range(N - 1)]
+    batch = 6
+    probs = []
+    for b in range(batch):
+        blocks = {k: [] for k in ("Q", "M", "R", "q", "r", "A", "B", "c", "delta")}
+        for n in sd:
+            S = rng.normal(size=(n, n))
+            blocks["Q"].append(S.T @ S + 1e-3 * np.eye(n))
+            blocks["q"].append(rng.normal(size=n))
+            blocks["c"].append(rng.normal(size=n))
+            blocks["delta"].append(1e-3 + 0.1 * rng.random(n))
+        for e, m in enumerate(cd):
+            np_, nc = sd[parents[e]], sd[children[e]]
+            G = rng.normal(size=(m, m))
+            blocks["A"].append(0.3 * rng.normal(size=(nc, np_)))
+            blocks["B"].append(0.3 * rng.normal(size=(nc, m)))
+            blocks["M"].append(0.05 * rng.normal(size=(np_, m)))
+            blocks["R"].append(G.T @ G + 1.01 * np.eye(m))
+            blocks["r"].append(rng.normal(size=m))
+        probs.append(blocks)
+    probs[3]["R"][2] = -np.eye(cd[2])  # G failure on instance 3
+    prob = dict(parents=parents, children=children, state_dims=sd, control_dims=cd)
+    s = _solver(dict(prob, blocks=None), batch=batch)
+    s.pack(probs)
+    st = s.factor()
+    s.solve()
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    for b in range(batch):
+        lqr = oracle_lib.TreeLQR(parents, children, sd, cd, probs[b])
+        assert lqr.factor() == st[b]
+        if st[b] != 0:
+            assert b == 3 and st[b] == 3
+            continue
+        xo, uo, yo = lqr.solve()
+        x, u, y = s.unpack_solution(b)
+        for a, bb in list(zip(x, xo)) + list(zip(u, uo)) + list(zip(y, yo)):
+            np.testing.assert_allclose(a, bb, rtol=0, atol=1e-11 * max(1.0, np.abs(bb).max()))
