@@ -1,0 +1,22 @@
+"""Runs the C++ re-expression of the reference's tests/lqr_test.cpp against the
+drop-in `sip::optimal_control::LQR` adapter (include/sip_optimal_control_amd/
+lqr_dropin.hpp) on the GPU: tests/cpp/test_dropin.cpp."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_dropin_suite():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    exe = entry.build_dropin_test()
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(proc.stdout)
+    print(proc.stderr)
+    assert proc.returncode == 0, proc.stdout[-3000:]
+    assert "0 failures" in proc.stdout
+    assert proc.stdout.count("[  OK  ]") >= 17
