@@ -79,8 +79,9 @@ typedef struct sip_lqr_plan sip_lqr_plan;
  * (lqr.cpp:635-643) for `batch` problems of horizon T (= num_edges), state
  * dimension n, control dimension m, on HIP device `device`.  The chain
  * topology is compiled here once, like the reference caches its traversal
- * (lqr.cpp:641,646).  Returns SIP_LQR_ERR_UNSUPPORTED when no kernel exists
- * for (dtype, n, m). */
+ * (lqr.cpp:641,646).  Every (dtype, n >= 1, m >= 1) is served: hot shapes by a
+ * dedicated fused kernel, everything else by the general engine (one
+ * wavefront per problem, see sip_lqr_kernel_name()). */
 int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
                         int device, sip_lqr_plan **plan);
 void sip_lqr_plan_destroy(sip_lqr_plan *plan);
@@ -134,7 +135,9 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
 
 /* Replaces: LQR::factor_with_status() alone (lqr.cpp:645-731; called by
  * CallbackProvider::factor, helpers.cpp:368).  Leaves the factor state in
- * d_workspace and the K part of d_gains for later sip_lqr_solve() calls. */
+ * d_workspace and the K part of d_gains for later sip_lqr_solve() calls.  The
+ * split entry points run on the general engine for every shape; its factor
+ * state is not interchangeable with the fused launch's spill. */
 int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
                    int32_t *d_status, void *d_workspace, void *stream);
 

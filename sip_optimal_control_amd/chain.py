@@ -53,7 +53,7 @@ class BatchedChainLQR:
         assert self._lib.sip_lqr_mats_len(handle) == self.shape.mats_len
         assert self._lib.sip_lqr_vecs_len(handle) == self.shape.vecs_len
         assert self._lib.sip_lqr_gains_len(handle) == self.shape.gains_len
-        ws_elems = self._lib.sip_lqr_workspace_bytes(handle) // esize
+        ws_elems = -(-self._lib.sip_lqr_workspace_bytes(handle) // esize)
         self.workspace = torch.empty(ws_elems, dtype=dtype, device=self.device)
         self.status = torch.zeros(self.batch, dtype=torch.int32, device=self.device)
 
@@ -95,6 +95,37 @@ class BatchedChainLQR:
             ctypes.c_void_p(self.workspace.data_ptr()),
             ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_factor_solve")
         return sol, gains, self.status
+
+    def factor(self, mats, gains=None, stream=None):
+        """LQR::factor_with_status() alone (general engine): statuses, K part of gains,
+        factor state kept in the workspace for later solve() calls."""
+        s = self.shape
+        if gains is None:
+            gains = self.empty_gains()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        _check(self._lib.sip_lqr_factor(
+            self._plan, self._ptr(mats, self.batch, s.mats_len, "mats"),
+            self._ptr(gains, self.batch, s.gains_len, "gains"),
+            ctypes.c_void_p(self.status.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()),
+            ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_factor")
+        return gains, self.status
+
+    def solve(self, mats, vecs, gains, sol=None, stream=None):
+        """LQR::solve() alone against the last factor(); repeatable with new vecs."""
+        s = self.shape
+        if sol is None:
+            sol = self.empty_sol()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        _check(self._lib.sip_lqr_solve(
+            self._plan, self._ptr(mats, self.batch, s.mats_len, "mats"),
+            self._ptr(vecs, self.batch, s.vecs_len, "vecs"),
+            self._ptr(sol, self.batch, s.vecs_len, "sol"),
+            self._ptr(gains, self.batch, s.gains_len, "gains"),
+            ctypes.c_void_p(self.workspace.data_ptr()),
+            ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_solve")
+        return sol
 
     def close(self):
         if getattr(self, "_plan", None):

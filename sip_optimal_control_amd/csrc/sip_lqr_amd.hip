@@ -7,19 +7,30 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <vector>
+
+#include <memory>
 
 #include "chain_qw16.hpp"
+#include "generic_plan.hpp"
 
 struct sip_lqr_plan {
   int dtype;
   int64_t batch;
   int T, n, m, device;
   const char *kernel_name;
-  int ws_slot; // scalars of workspace per node
-  // fused factor+solve launcher
+  int ws_slot; // scalars of workspace per node of the fused kernel (0: none)
+  // fused factor+solve launcher of a dedicated kernel; nullptr: the general
+  // engine (tree_generic.hpp) runs factor then solve
   hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
                           void *, void *, int32_t *, void *, hipStream_t);
+  // General engine on the packed chain layout: serves shapes / dtypes without
+  // a dedicated kernel and the split factor / solve entry points.  Tables are
+  // laid out at plan creation (host only), uploaded at first use.
+  mutable sipamd::GenericPlan gen;
+  mutable bool gen_uploaded = false;
 };
 
 #ifdef SIP_LQR_STAMPS
@@ -95,6 +106,50 @@ size_t scalar_size(const sip_lqr_plan *p) {
   return p->dtype == SIP_LQR_F32 ? sizeof(float) : sizeof(double);
 }
 
+// Chain topology (Topology::set_chain, lqr.cpp:32-40) for the general engine.
+void init_generic(sip_lqr_plan *p) {
+  const int T = p->T, N = T + 1;
+  std::vector<int> sd(N, p->n), cd(T, p->m), pa(T), ch(T), marks(N);
+  for (int e = 0; e < T; ++e)
+    pa[e] = e, ch[e] = e + 1;
+  sipamd::GenericPlan &g = p->gen;
+  g.set_shape(T, 0, sd.data(), cd.data());
+  g.parents.assign(T, 0), g.children.assign(T, 0);
+  g.child_offsets.assign(N + 1, 0), g.child_edges.assign(T, 0);
+  g.preorder.assign(N, 0), g.postorder.assign(N, 0);
+  (void)sip_lqr_compile_topology(T, 0, pa.data(), ch.data(), g.child_offsets.data(),
+                                 g.child_edges.data(), g.parents.data(), g.children.data(),
+                                 g.preorder.data(), g.postorder.data(), marks.data());
+  g.layout_chain(p->n, p->m, T);
+}
+
+hipError_t ensure_generic(const sip_lqr_plan *p) {
+  if (p->gen_uploaded)
+    return hipSuccess;
+  const hipError_t e = p->gen.upload(p->device);
+  if (e == hipSuccess)
+    p->gen_uploaded = true;
+  return e;
+}
+
+// Bytes of the general engine's work arena, plus the status copy it keeps for
+// sip_lqr_solve (which has no status argument).
+size_t generic_ws_bytes(const sip_lqr_plan *p) {
+  const size_t body = (size_t)p->batch * (size_t)p->gen.ws_len * scalar_size(p);
+  return (body + 15) / 16 * 16 + (size_t)p->batch * sizeof(int32_t);
+}
+int32_t *generic_status(const sip_lqr_plan *p, void *ws) {
+  const size_t body = (size_t)p->batch * (size_t)p->gen.ws_len * scalar_size(p);
+  return (int32_t *)((char *)ws + (body + 15) / 16 * 16);
+}
+
+int report(hipError_t e, const char *what) {
+  if (e == hipSuccess)
+    return SIP_LQR_OK;
+  std::fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e));
+  return SIP_LQR_ERR_HIP;
+}
+
 } // namespace
 
 extern "C" {
@@ -107,9 +162,11 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
   if (batch < 1 || T < 0 || n < 1 || m < 1 ||
       (dtype != SIP_LQR_F64 && dtype != SIP_LQR_F32))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
-  const KernelEntry *k = find_kernel(dtype, n, m);
-  if (k == nullptr)
-    return SIP_LQR_ERR_UNSUPPORTED;
+  const char *want = std::getenv("SIP_LQR_VARIANT");
+  const bool force_general = want != nullptr && std::strcmp(want, "general") == 0;
+  const KernelEntry *k = force_general ? nullptr : find_kernel(dtype, n, m);
+  if (k == nullptr && want != nullptr && want[0] != 0 && !force_general)
+    return SIP_LQR_ERR_UNSUPPORTED; // an explicitly requested variant does not exist
   sip_lqr_plan *p = new (std::nothrow) sip_lqr_plan;
   if (p == nullptr)
     return SIP_LQR_ERR_ALLOC;
@@ -119,9 +176,11 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
   p->n = n;
   p->m = m;
   p->device = device;
-  p->kernel_name = k->name;
-  p->ws_slot = k->ws_slot;
-  p->launch_fs = k->launch_fs;
+  p->kernel_name = k ? k->name : (dtype == SIP_LQR_F32 ? "tree_generic(chain layout)/f32"
+                                                       : "tree_generic(chain layout)/f64");
+  p->ws_slot = k ? k->ws_slot : 0;
+  p->launch_fs = k ? k->launch_fs : nullptr;
+  init_generic(p);
   *plan = p;
   return SIP_LQR_OK;
 }
@@ -156,8 +215,10 @@ size_t sip_lqr_status_bytes(const sip_lqr_plan *p) {
   return (size_t)p->batch * sizeof(int32_t);
 }
 size_t sip_lqr_workspace_bytes(const sip_lqr_plan *p) {
-  return (size_t)p->batch * ((size_t)p->T + 1) * (size_t)p->ws_slot *
-         scalar_size(p);
+  // one buffer serves the fused kernel and the general engine (never both at
+  // once): the larger of the two
+  const size_t fused = (size_t)p->batch * ((size_t)p->T + 1) * (size_t)p->ws_slot * scalar_size(p);
+  return std::max(fused, generic_ws_bytes(p));
 }
 
 } // extern "C"
@@ -277,26 +338,53 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
   if (plan == nullptr || !d_mats || !d_vecs || !d_sol || !d_status ||
       !d_workspace || (plan->T > 0 && !d_gains))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
-  if (plan->launch_fs == nullptr)
-    return SIP_LQR_ERR_UNSUPPORTED;
-  const hipError_t e = plan->launch_fs(plan, d_mats, d_vecs, d_sol, d_gains,
-                                       d_status, d_workspace,
-                                       (hipStream_t)stream);
-  if (e != hipSuccess) {
-    std::fprintf(stderr, "sip_lqr_factor_solve: %s\n", hipGetErrorString(e));
-    return SIP_LQR_ERR_HIP;
-  }
-  return SIP_LQR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (plan->launch_fs != nullptr)
+    return report(plan->launch_fs(plan, d_mats, d_vecs, d_sol, d_gains, d_status, d_workspace, s),
+                  "sip_lqr_factor_solve");
+  // no dedicated kernel for this shape / dtype: general engine, two launches
+  hipError_t e = ensure_generic(plan);
+  if (e == hipSuccess)
+    e = plan->dtype == SIP_LQR_F32
+            ? plan->gen.launch_factor<float>(plan->batch, d_mats, d_workspace, d_gains, d_status, s)
+            : plan->gen.launch_factor<double>(plan->batch, d_mats, d_workspace, d_gains, d_status, s);
+  if (e == hipSuccess)
+    e = plan->dtype == SIP_LQR_F32
+            ? plan->gen.launch_solve<float>(plan->batch, d_mats, d_vecs, d_workspace, d_gains, d_sol, d_status, s)
+            : plan->gen.launch_solve<double>(plan->batch, d_mats, d_vecs, d_workspace, d_gains, d_sol, d_status, s);
+  return report(e, "sip_lqr_factor_solve(general)");
 }
 
-int sip_lqr_factor(const sip_lqr_plan *, const void *, void *, int32_t *,
-                   void *, void *) {
-  return SIP_LQR_ERR_UNSUPPORTED; // split factor/solve kernels: not built yet
+// Split entry points: always the general engine (its work arena holds the
+// reference's factor state W, G_factor, V, F_factor, sqrt_delta(_inv), v).
+int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
+                   int32_t *d_status, void *d_workspace, void *stream) {
+  if (plan == nullptr || !d_mats || !d_status || !d_workspace || (plan->T > 0 && !d_gains))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = ensure_generic(plan);
+  if (e == hipSuccess)
+    e = plan->dtype == SIP_LQR_F32
+            ? plan->gen.launch_factor<float>(plan->batch, d_mats, d_workspace, d_gains, d_status, s)
+            : plan->gen.launch_factor<double>(plan->batch, d_mats, d_workspace, d_gains, d_status, s);
+  if (e == hipSuccess) // keep the statuses for sip_lqr_solve
+    e = hipMemcpyAsync(generic_status(plan, d_workspace), d_status, (size_t)plan->batch * sizeof(int32_t),
+                       hipMemcpyDeviceToDevice, s);
+  return report(e, "sip_lqr_factor");
 }
 
-int sip_lqr_solve(const sip_lqr_plan *, const void *, const void *, void *,
-                  void *, void *, void *) {
-  return SIP_LQR_ERR_UNSUPPORTED;
+int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats, const void *d_vecs, void *d_sol,
+                  void *d_gains, void *d_workspace, void *stream) {
+  if (plan == nullptr || !d_mats || !d_vecs || !d_sol || !d_workspace || (plan->T > 0 && !d_gains))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = ensure_generic(plan);
+  const int32_t *st = generic_status(plan, d_workspace);
+  if (e == hipSuccess)
+    e = plan->dtype == SIP_LQR_F32
+            ? plan->gen.launch_solve<float>(plan->batch, d_mats, d_vecs, d_workspace, d_gains, d_sol, st, s)
+            : plan->gen.launch_solve<double>(plan->batch, d_mats, d_vecs, d_workspace, d_gains, d_sol, st, s);
+  return report(e, "sip_lqr_solve");
 }
 
 const char *sip_lqr_kernel_name(const sip_lqr_plan *plan) {

@@ -9,20 +9,13 @@
 #include <new>
 #include <vector>
 
-#include "tree_generic.hpp"
+#include "generic_plan.hpp"
 
 struct sip_lqr_tree_plan {
   int64_t batch = 0;
-  int num_edges = 0, num_nodes = 0, root = 0, device = 0;
+  int device = 0;
   int topology_status = SIP_LQR_INVALID_TOPOLOGY;
-  std::vector<int> state_dims, control_dims, parents, children;
-  std::vector<int> child_offsets, child_edges, preorder, postorder;
-  std::vector<long> node_in, edge_in, node_ws, edge_ws, node_out, edge_out;
-  long in_len = 0, ws_len = 0, out_len = 0, scratch_ws = 0;
-  int max_n = 0, max_m = 0;
-  void *d_ints = nullptr;  // all int tables
-  void *d_longs = nullptr; // all offset tables
-  sipamd::tree::Meta meta{};
+  sipamd::GenericPlan g;
 };
 
 extern "C" {
@@ -99,107 +92,31 @@ int sip_lqr_tree_plan_create(int64_t batch, int num_edges, int root,
   if (p == nullptr)
     return SIP_LQR_ERR_ALLOC;
   p->batch = batch;
-  p->num_edges = E;
-  p->num_nodes = N;
-  p->root = root;
   p->device = device;
-  p->state_dims.assign(state_dims, state_dims + N);
-  p->control_dims.assign(control_dims, control_dims + E);
-  p->parents.assign(E, 0);
-  p->children.assign(E, 0);
-  p->child_offsets.assign(N + 1, 0);
-  p->child_edges.assign(E, 0);
-  p->preorder.assign(N, 0);
-  p->postorder.assign(N, 0);
+  sipamd::GenericPlan &g = p->g;
+  g.set_shape(E, root, state_dims, control_dims);
+  g.parents.assign(E, 0), g.children.assign(E, 0);
+  g.child_offsets.assign(N + 1, 0), g.child_edges.assign(E, 0);
+  g.preorder.assign(N, 0), g.postorder.assign(N, 0);
   std::vector<int> marks(N, 0);
   p->topology_status = sip_lqr_compile_topology(
-      E, root, edge_parents, edge_children, p->child_offsets.data(),
-      p->child_edges.data(), p->parents.data(), p->children.data(),
-      p->preorder.data(), p->postorder.data(), marks.data());
+      E, root, edge_parents, edge_children, g.child_offsets.data(), g.child_edges.data(),
+      g.parents.data(), g.children.data(), g.preorder.data(), g.postorder.data(), marks.data());
   *out = p;
   if (p->topology_status != SIP_LQR_SUCCESS)
     return SIP_LQR_OK; // latched, reported by factor (lqr.cpp:646-648)
-
-  p->max_n = N ? *std::max_element(p->state_dims.begin(), p->state_dims.end()) : 0;
-  p->max_m = E ? *std::max_element(p->control_dims.begin(), p->control_dims.end()) : 0;
-  p->node_in.resize(N), p->node_ws.resize(N), p->node_out.resize(N);
-  p->edge_in.resize(E), p->edge_ws.resize(E), p->edge_out.resize(E);
-  long in = 0, ws = 0, o = 0;
-  for (int i = 0; i < N; ++i) {
-    const long n = p->state_dims[i];
-    p->node_in[i] = in, in += n * n + 3 * n;
-    p->node_out[i] = o, o += 2 * n;
-  }
-  for (int e = 0; e < E; ++e) {
-    const long np = p->state_dims[p->parents[e]], nc = p->state_dims[p->children[e]],
-               m = p->control_dims[e];
-    p->edge_in[e] = in, in += nc * np + nc * m + np * m + m * m + m;
-    p->edge_out[e] = o, o += m;
-    p->edge_ws[e] = ws, ws += (long)p->max_n * p->max_n + m * np + m * m + m;
-  }
-  for (int i = 0; i < N; ++i) {
-    const long n = p->state_dims[i];
-    p->node_ws[i] = ws, ws += 2 * n * n + 3 * n;
-  }
-  p->scratch_ws = ws;
-  ws += (long)p->max_m * p->max_n + (long)p->max_n * p->max_n + 2L * p->max_n + p->max_m;
-  p->in_len = in, p->ws_len = ws, p->out_len = o;
-
-  // upload the tables
-  std::vector<int> ints;
-  auto push_i = [&](const std::vector<int> &v) {
-    const size_t at = ints.size();
-    ints.insert(ints.end(), v.begin(), v.end());
-    return at;
-  };
-  const size_t o_sd = push_i(p->state_dims), o_cd = push_i(p->control_dims),
-               o_pa = push_i(p->parents), o_ch = push_i(p->children),
-               o_co = push_i(p->child_offsets), o_ce = push_i(p->child_edges),
-               o_pre = push_i(p->preorder), o_post = push_i(p->postorder);
-  std::vector<long> longs;
-  auto push_l = [&](const std::vector<long> &v) {
-    const size_t at = longs.size();
-    longs.insert(longs.end(), v.begin(), v.end());
-    return at;
-  };
-  const size_t l_ni = push_l(p->node_in), l_ei = push_l(p->edge_in),
-               l_nw = push_l(p->node_ws), l_ew = push_l(p->edge_ws),
-               l_no = push_l(p->node_out), l_eo = push_l(p->edge_out);
-  if (hipSetDevice(device) != hipSuccess ||
-      hipMalloc(&p->d_ints, std::max<size_t>(1, ints.size()) * sizeof(int)) != hipSuccess ||
-      hipMalloc(&p->d_longs, std::max<size_t>(1, longs.size()) * sizeof(long)) != hipSuccess ||
-      hipMemcpy(p->d_ints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(p->d_longs, longs.data(), longs.size() * sizeof(long), hipMemcpyHostToDevice) != hipSuccess) {
-    std::fprintf(stderr, "sip_lqr_tree_plan_create: HIP error: %s\n",
-                 hipGetErrorString(hipGetLastError()));
-    sip_lqr_tree_plan_destroy(p);
+  g.layout_tree_native();
+  const hipError_t e = g.upload(device);
+  if (e != hipSuccess) {
+    std::fprintf(stderr, "sip_lqr_tree_plan_create: HIP error: %s\n", hipGetErrorString(e));
+    delete p;
     *out = nullptr;
     return SIP_LQR_ERR_HIP;
   }
-  const int *di = (const int *)p->d_ints;
-  const long *dl = (const long *)p->d_longs;
-  sipamd::tree::Meta &m = p->meta;
-  m.num_edges = E, m.num_nodes = N, m.root = root, m.max_n = p->max_n, m.max_m = p->max_m;
-  m.state_dims = di + o_sd, m.control_dims = di + o_cd;
-  m.edge_parents = di + o_pa, m.edge_children = di + o_ch;
-  m.child_offsets = di + o_co, m.child_edges = di + o_ce;
-  m.preorder = di + o_pre, m.postorder = di + o_post;
-  m.node_in = dl + l_ni, m.edge_in = dl + l_ei, m.node_ws = dl + l_nw;
-  m.edge_ws = dl + l_ew, m.node_out = dl + l_no, m.edge_out = dl + l_eo;
-  m.scratch_ws = p->scratch_ws;
-  m.in_len = p->in_len, m.ws_len = p->ws_len, m.out_len = p->out_len;
   return SIP_LQR_OK;
 }
 
-void sip_lqr_tree_plan_destroy(sip_lqr_tree_plan *plan) {
-  if (plan == nullptr)
-    return;
-  if (plan->d_ints)
-    (void)hipFree(plan->d_ints);
-  if (plan->d_longs)
-    (void)hipFree(plan->d_longs);
-  delete plan;
-}
+void sip_lqr_tree_plan_destroy(sip_lqr_tree_plan *plan) { delete plan; }
 
 int sip_lqr_tree_topology_status(const sip_lqr_tree_plan *plan) {
   return plan ? plan->topology_status : SIP_LQR_INVALID_TOPOLOGY;
@@ -209,25 +126,24 @@ const int *sip_lqr_tree_topology_array(const sip_lqr_tree_plan *plan, int which)
   if (plan == nullptr)
     return nullptr;
   switch (which) {
-  case 0: return plan->child_offsets.data();
-  case 1: return plan->child_edges.data();
-  case 2: return plan->preorder.data();
-  case 3: return plan->postorder.data();
+  case 0: return plan->g.child_offsets.data();
+  case 1: return plan->g.child_edges.data();
+  case 2: return plan->g.preorder.data();
+  case 3: return plan->g.postorder.data();
   default: return nullptr;
   }
 }
 
-size_t sip_lqr_tree_input_len(const sip_lqr_tree_plan *p) { return p ? (size_t)p->in_len : 0; }
-size_t sip_lqr_tree_work_len(const sip_lqr_tree_plan *p) { return p ? (size_t)p->ws_len : 0; }
-size_t sip_lqr_tree_output_len(const sip_lqr_tree_plan *p) { return p ? (size_t)p->out_len : 0; }
+size_t sip_lqr_tree_input_len(const sip_lqr_tree_plan *p) { return p ? (size_t)p->g.in0_len : 0; }
+size_t sip_lqr_tree_work_len(const sip_lqr_tree_plan *p) { return p ? (size_t)p->g.ws_len : 0; }
+size_t sip_lqr_tree_output_len(const sip_lqr_tree_plan *p) { return p ? (size_t)p->g.out_len : 0; }
 
 size_t sip_lqr_tree_offset(const sip_lqr_tree_plan *p, int arena, int kind, int index) {
   if (p == nullptr || p->topology_status != SIP_LQR_SUCCESS || arena < 0 || arena > 2 ||
-      kind < 0 || kind > 1 || index < 0 || index >= (kind == 0 ? p->num_nodes : p->num_edges))
+      kind < 0 || kind > 1 || index < 0 || index >= (kind == 0 ? p->g.N : p->g.E))
     return (size_t)-1;
-  const std::vector<long> *tab[3][2] = {{&p->node_in, &p->edge_in},
-                                       {&p->node_ws, &p->edge_ws},
-                                       {&p->node_out, &p->edge_out}};
+  // first block of each (arena, kind) group: Q.. / A.. ; W.. / V.. ; x.. / u
+  const std::vector<long> *tab[3][2] = {{&p->g.oQ, &p->g.oA}, {&p->g.oV, &p->g.oW}, {&p->g.ox, &p->g.ou}};
   return (size_t)(*tab[arena][kind])[index];
 }
 
@@ -244,12 +160,9 @@ int sip_lqr_tree_factor(const sip_lqr_tree_plan *plan, const double *d_input,
       return SIP_LQR_ERR_HIP;
     return SIP_LQR_OK;
   }
-  if ((d_input == nullptr && plan->in_len > 0) || d_work == nullptr)
+  if ((d_input == nullptr && plan->g.in0_len > 0) || d_work == nullptr)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(sipamd::tree::factor_kernel, dim3((unsigned)plan->batch),
-                     dim3(sipamd::tree::TPB), 0, s, plan->meta, d_input, d_work,
-                     (int *)d_status, (long)plan->batch);
-  const hipError_t e = hipGetLastError();
+  const hipError_t e = plan->g.launch_factor<double>((long)plan->batch, d_input, d_work, d_work, d_status, s);
   if (e != hipSuccess) {
     std::fprintf(stderr, "sip_lqr_tree_factor: %s\n", hipGetErrorString(e));
     return SIP_LQR_ERR_HIP;
@@ -261,14 +174,12 @@ int sip_lqr_tree_solve(const sip_lqr_tree_plan *plan, const double *d_input,
                        double *d_work, double *d_output, const int32_t *d_status,
                        void *stream) {
   if (plan == nullptr || d_status == nullptr || d_work == nullptr ||
-      (d_output == nullptr && plan->out_len > 0) || (d_input == nullptr && plan->in_len > 0))
+      (d_output == nullptr && plan->g.out_len > 0) || (d_input == nullptr && plan->g.in0_len > 0))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   if (plan->topology_status != SIP_LQR_SUCCESS)
     return SIP_LQR_ERR_INVALID_ARGUMENT; // solve() needs a successful factor
-  hipLaunchKernelGGL(sipamd::tree::solve_kernel, dim3((unsigned)plan->batch),
-                     dim3(sipamd::tree::TPB), 0, (hipStream_t)stream, plan->meta,
-                     d_input, d_work, d_output, (const int *)d_status, (long)plan->batch);
-  const hipError_t e = hipGetLastError();
+  const hipError_t e = plan->g.launch_solve<double>((long)plan->batch, d_input, d_input, d_work, d_work,
+                                                    d_output, d_status, (hipStream_t)stream);
   if (e != hipSuccess) {
     std::fprintf(stderr, "sip_lqr_tree_solve: %s\n", hipGetErrorString(e));
     return SIP_LQR_ERR_HIP;

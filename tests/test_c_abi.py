@@ -54,8 +54,18 @@ def test_plan_sizes_and_errors(lib):
     assert s.algorithmic_bytes(8) == 209632
     assert b"qw16" in lib.sip_lqr_kernel_name(h)
     lib.sip_lqr_plan_destroy(h)
-    # unsupported shape -> SIP_LQR_ERR_UNSUPPORTED, never a silent fallback
-    assert lib.sip_lqr_plan_create(0, 8, 5, 99, 3, 0, ctypes.byref(h)) == -2
+    # shapes without a dedicated kernel go to the general GPU engine (never to the host)
+    assert lib.sip_lqr_plan_create(0, 8, 5, 19, 3, 0, ctypes.byref(h)) == 0
+    assert b"tree_generic" in lib.sip_lqr_kernel_name(h)
+    lib.sip_lqr_plan_destroy(h)
+    assert lib.sip_lqr_plan_create(1, 8, 100, 32, 8, 0, ctypes.byref(h)) == 0   # C4 shape, fp32
+    assert lib.sip_lqr_mats_bytes(h) + lib.sip_lqr_vecs_bytes(h) == 8 * 273920 * 4
+    lib.sip_lqr_plan_destroy(h)
+    os.environ["SIP_LQR_VARIANT"] = "no-such-variant"
+    try:
+        assert lib.sip_lqr_plan_create(0, 8, 5, 12, 4, 0, ctypes.byref(h)) == -2
+    finally:
+        del os.environ["SIP_LQR_VARIANT"]
     assert lib.sip_lqr_plan_create(0, 0, 5, 12, 4, 0, ctypes.byref(h)) == -1
     assert lib.sip_lqr_plan_create(7, 8, 5, 12, 4, 0, ctypes.byref(h)) == -1
 

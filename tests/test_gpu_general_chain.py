@@ -1,0 +1,138 @@
+"""The general GPU engine behind the chain C ABI: shapes / dtypes without a
+dedicated kernel, the split factor()/solve() entry points, fp32 (BASELINE C4).
+
+fp64 tolerance: 1e-9 max-abs relative (as everywhere).  fp32 is judged the way
+SURVEY.md 8(c) prescribes: KKT residual of the fp32 solution, evaluated in
+fp64, relative to the norm of the KKT right-hand side -- measured ~1e-5 at
+C4 (n=32, m=8, T=100, delta >= 1e-3); asserted < 2e-4."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dense_kkt
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    scale = np.abs(b).max(axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    return (np.abs(a - b) / scale).max()
+
+
+def _make(n, m, T, batch, seed, dtype=None):
+    from sip_optimal_control_amd import ChainShape, synthetic
+    dtype = dtype or torch.float64
+    return synthetic.make_chain_batch(ChainShape(n, m, T), batch, seed=seed, device="cuda:0",
+                                      dtype=dtype, cross_term=0.01)
+
+
+@pytest.mark.parametrize("n,m,T,batch", [(16, 4, 16, 5), (5, 3, 7, 9), (7, 1, 4, 3), (15, 16, 3, 2)])
+def test_general_engine_fp64_matches_oracle(oracle_lib, n, m, T, batch):
+    from sip_optimal_control_amd import BatchedChainLQR
+    mats, vecs = _make(n, m, T, batch, seed=50 + n)
+    solver = BatchedChainLQR(n, m, T, batch)
+    if (n, m) != (15, 16):
+        assert "tree_generic" in solver.kernel_name
+    sol, gains, status = solver.factor_solve(mats, vecs)
+    torch.cuda.synchronize()
+    ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats.cpu().numpy(), vecs.cpu().numpy())
+    np.testing.assert_array_equal(status.cpu().numpy(), ref_status)
+    assert _rel(sol.cpu().numpy(), ref_sol) <= 1e-9
+    assert _rel(gains.cpu().numpy(), ref_gains) <= 1e-9
+
+
+def test_forced_general_engine_equals_fused_kernel(oracle_lib):
+    """Same C3-shaped inputs through the dedicated fused kernel and through the general engine."""
+    from sip_optimal_control_amd import BatchedChainLQR
+    n, m, T, batch = 12, 4, 50, 17
+    mats, vecs = _make(n, m, T, batch, seed=9)
+    fused = BatchedChainLQR(n, m, T, batch)
+    os.environ["SIP_LQR_VARIANT"] = "general"
+    try:
+        general = BatchedChainLQR(n, m, T, batch)
+    finally:
+        del os.environ["SIP_LQR_VARIANT"]
+    assert "qw16" in fused.kernel_name and "tree_generic" in general.kernel_name
+    s1, g1, _ = fused.factor_solve(mats, vecs)
+    s2, g2, _ = general.factor_solve(mats, vecs)
+    torch.cuda.synchronize()
+    assert _rel(s1.cpu().numpy(), s2.cpu().numpy()) <= 1e-9
+    assert _rel(g1.cpu().numpy(), g2.cpu().numpy()) <= 1e-9
+
+
+def test_split_factor_then_repeated_solve(oracle_lib):
+    """sip_lqr_factor once, sip_lqr_solve twice with different right-hand sides
+    (tests/lqr_test.cpp:431-450; CallbackProvider::factor / ::solve)."""
+    from sip_optimal_control_amd import BatchedChainLQR
+    n, m, T, batch = 12, 4, 20, 6
+    mats, vecs = _make(n, m, T, batch, seed=77)
+    _, vecs2 = _make(n, m, T, batch, seed=78)
+    solver = BatchedChainLQR(n, m, T, batch)
+    gains, status = solver.factor(mats)
+    sol_a = solver.solve(mats, vecs, gains).clone()
+    k_a = gains.clone()
+    sol_b = solver.solve(mats, vecs2, gains).clone()
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 0).all()
+    for v, s, g in ((vecs, sol_a, k_a), (vecs2, sol_b, gains)):
+        ref_sol, ref_gains, _ = oracle_lib.chain_batch(n, m, T, mats.cpu().numpy(), v.cpu().numpy())
+        assert _rel(s.cpu().numpy(), ref_sol) <= 1e-9
+        assert _rel(g.cpu().numpy(), ref_gains) <= 1e-9
+
+
+def test_split_solve_skips_failed_problems(oracle_lib):
+    from sip_optimal_control_amd import BatchedChainLQR, ChainShape
+    n, m, T, batch = 4, 2, 5, 4
+    shape = ChainShape(n, m, T)
+    mats, vecs = _make(n, m, T, batch, seed=3)
+    bad = mats.clone()
+    off = shape.mats_off(2)["R"]
+    bad[1, off:off + m * m] = -torch.eye(m, dtype=torch.float64, device="cuda:0").reshape(-1)   # G failure
+    bad[2, shape.mats_off(T)["delta"]] = 0.0                                                     # invalid delta
+    solver = BatchedChainLQR(n, m, T, batch)
+    gains, status = solver.factor(bad)
+    sol = solver.empty_sol().fill_(-7.0)
+    solver.solve(bad, vecs, gains, sol)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert list(st) == [0, 3, 1, 0]
+    ref_sol, _, ref_status = oracle_lib.chain_batch(n, m, T, bad.cpu().numpy(), vecs.cpu().numpy())
+    np.testing.assert_array_equal(st, ref_status)
+    out = sol.cpu().numpy()
+    assert (out[1] == -7.0).all() and (out[2] == -7.0).all()       # untouched, like the oracle
+    assert _rel(out[[0, 3]], ref_sol[[0, 3]]) <= 1e-9
+    # the fused launch reports the same statuses
+    _, _, st2 = solver.factor_solve(bad, vecs)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(st2.cpu().numpy(), ref_status)
+
+
+def test_fp32_c4_shape_kkt_residual(oracle_lib):
+    """BASELINE config 4 shape (n=32, m=8, T=100, fp32), small batch."""
+    from sip_optimal_control_amd import BatchedChainLQR
+    n, m, T, batch = 32, 8, 100, 4
+    mats64, vecs64 = _make(n, m, T, batch, seed=1000)
+    mats, vecs = mats64.float(), vecs64.float()
+    solver = BatchedChainLQR(n, m, T, batch, dtype=torch.float32)
+    assert solver.kernel_name.endswith("/f32")
+    sol, gains, status = solver.factor_solve(mats, vecs)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 0).all()
+    par, ch = list(range(T)), list(range(1, T + 1))
+    worst = 0.0
+    for p in range(batch):
+        # residual of the fp32 solution against the fp32-rounded problem, in fp64
+        blocks = dense_kkt.chain_blocks_from_packed(n, m, T, mats[p].double().cpu().numpy(),
+                                                    vecs[p].double().cpu().numpy())
+        x, u, y = dense_kkt.chain_sol_from_packed(n, m, T, sol[p].double().cpu().numpy())
+        res = dense_kkt.residual_norm(par, ch, [n] * (T + 1), [m] * T, blocks, x, u, y)
+        rhs = np.sqrt(sum(float(v @ v) for k in ("q", "r", "c") for v in blocks[k]))
+        worst = max(worst, res / rhs)
+    print("fp32 C4 relative KKT residual:", worst)
+    assert worst < 2e-4, worst
+    # and close to the fp64 oracle solution of the same (rounded) problem
+    ref_sol, _, _ = oracle_lib.chain_batch(n, m, T, mats.double().cpu().numpy(), vecs.double().cpu().numpy())
+    assert _rel(sol.double().cpu().numpy(), ref_sol) < 5e-3
