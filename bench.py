@@ -118,9 +118,8 @@ def main():
     batch, T, n, m, dt = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    if dt != "f64":
-        raise SystemExit(f"workload {args.workload}: dtype {dt} has no kernel yet")
-    dtype = torch.float64
+    dtype = torch.float64 if dt == "f64" else torch.float32
+    esize = 8 if dt == "f64" else 4
     shape = ChainShape(n, m, T)
     mats, vecs = synthetic.make_chain_batch(shape, batch, seed=1234 + rank, device=device, dtype=dtype)
     solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device=device)
@@ -174,7 +173,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))
 
     if rank == 0:
-        alg_bytes = shape.algorithmic_bytes(8)
+        alg_bytes = shape.algorithmic_bytes(esize)
         achieved = alg_bytes * batch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

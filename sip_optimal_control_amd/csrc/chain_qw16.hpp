@@ -88,11 +88,13 @@ __device__ __forceinline__ double rcp_nr(double d) {
 template <int S>
 __device__ __forceinline__ bool chol_ldl_dpp(double (&A)[S], double (&dinv)[S],
                                              const int c) {
-  bool fail = false;
+  // The pivot is replicated over its row, so the comparison result is
+  // row-uniform: collect it as a wave mask (one v_cmp + one s_or per pivot).
+  unsigned long long failmask = 0;
   sfor<0, S>([&](auto kk) {
     constexpr int k = decltype(kk)::value;
     const double d = bcast<k>(A[k]);
-    fail |= (d <= 0.0);
+    failmask |= __ballot(d <= 0.0);
     const double y2 = rcp_nr(d);
     dinv[k] = y2;
     // lane j > k: Lt(j,k) / d_k (by symmetry its own A[k] is Lt(j,k))
@@ -100,7 +102,7 @@ __device__ __forceinline__ bool chol_ldl_dpp(double (&A)[S], double (&dinv)[S],
     // A(i,j) -= Lt(i,k) Lt(j,k) / d_k, i > k, lanes j > k
     rank1<S - k - 1, k, true, false>(A + k + 1, A + k + 1, upd);
   });
-  return fail;
+  return ((failmask >> (__lane_id() & 63)) & 1ull) != 0;
 }
 
 // X <- (Lt D^-1 Lt^T)^{-1} X for X held one column per lane (any lane of the
@@ -177,7 +179,18 @@ typedef const __attribute__((address_space(3))) double lds_cdouble;
     __builtin_amdgcn_sched_barrier(0);                                         \
   } while (0)
 #define SIP_STAMP_ARG , unsigned long long *__restrict__ stamps
+// per-segment accumulation: seg[k] += now - last; last = now
+#define SIP_SEG(k)                                                             \
+  do {                                                                         \
+    unsigned long long now_;                                                   \
+    SIP_STAMP(now_);                                                           \
+    seg[k] += now_ - seg_last;                                                 \
+    seg_last = now_;                                                           \
+  } while (0)
 #else
+#define SIP_SEG(k)                                                             \
+  do {                                                                         \
+  } while (0)
 #define SIP_STAMP(var)                                                         \
   do {                                                                         \
   } while (0)
@@ -278,6 +291,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
                      acc_fwait = 0;
   (void)ts_begin, (void)ts_term, (void)ts_bwd, (void)ts_root, (void)ts_end,
       (void)ts_a, (void)ts_b, (void)acc_bwait, (void)acc_fwait;
+  unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, seg_last = 0;
+  (void)seg, (void)seg_last;
   SIP_STAMP(ts_begin);
   static_assert(!STAGED || C::OK, "staged kernel needs even N and M");
   constexpr int STG = L::NODE + L::EDGE;    // mats stage stride
@@ -322,6 +337,15 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   int stat = 0;
   double W[N], V[N], t[N], vch[N];
 
+  // Buffer view of this wave's rows of the workspace (packed-W spill).
+  const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(wsp + p0 * ws_len), 0, (int)((max_rel + 1) * ws_len * 8), 0x00020000);
+  // byte offset of W(0, c) of lane c's column inside the wave's view
+  // (out of range for lanes that never store)
+  const int wstore_base = (valid && isM)
+                              ? (int)(rr * ws_len * 8) + (c * N - (c * (c - 1)) / 2 - c) * 8
+                              : 0x7ffff000;
+
   // Loads [Q_i | q_i] as the augmented column, delta_i per lane, and on the
   // vector lane c_i, delta_i as columns.  nm / nv: stage block of mats / vecs.
   auto load_node = [&](auto nm, auto nv, double(&Vq)[N], double &dl,
@@ -350,23 +374,27 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       t[r] = cv[r] - dv[r] * V[r]; // -(f) = c - delta o v, lqr.cpp:778-779
       vch[r] = V[r];
     });
+    SIP_SEG(7);
     const bool ffail = node_factor<N>(V, dl, c, E, W);
+    SIP_SEG(8);
     if (stat == 0 && ffail)
       stat = 2; // F_FACTORIZATION_FAILURE
-    if (valid && isM) {
-      if constexpr (WPACK) {
-        // column c of the lower triangle: rows c..N-1, packed by columns
-        double *wn = pw + (long)i * WSN + (c * N - (c * (c - 1)) / 2 - c);
-        sfor<0, N>([&](auto ii) {
-          constexpr int r = decltype(ii)::value;
-          if (r >= c)
-            wn[r] = W[r];
-        });
-      } else {
-        double *wn = pw + (long)i * WSN + c * N;
-        sfor<0, N>(
-            [&](auto ii) { wn[decltype(ii)::value] = W[decltype(ii)::value]; });
-      }
+    if constexpr (WPACK) {
+      // Column c of the lower triangle (rows c..N-1), packed by columns.
+      // Ragged and lane-dependent, so instead of 12 exec-masked stores the
+      // unwanted (row < c, vector lane, tail rows) lanes get an out-of-range
+      // buffer offset: the range check of the buffer store drops them.
+      sfor<0, N>([&](auto ii) {
+        constexpr int r = decltype(ii)::value;
+        const int vo = (r >= c) ? wstore_base : 0x7ffff000;
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, W[r]), ws_rsrc, vo + r * 8,
+                                              i * (WSN * 8), 0);
+      });
+    } else if (valid && isM) {
+      double *wn = pw + (long)i * WSN + c * N;
+      sfor<0, N>(
+          [&](auto ii) { wn[decltype(ii)::value] = W[decltype(ii)::value]; });
     }
   };
 
@@ -393,6 +421,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
           [&](auto ii) { gn[decltype(ii)::value] = F[decltype(ii)::value]; });
     }
 
+    SIP_SEG(2);
     // H_child = B^T W (lqr.cpp:692); G = R + H_child B (lqr.cpp:693-694)
     double Hc[M], G[M], rinvG[M];
     sfor<0, M>([&](auto jj) { Hc[decltype(jj)::value] = 0.0; });
@@ -400,7 +429,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     sfor<0, M>(
         [&](auto jj) { G[decltype(jj)::value] = Rcol[decltype(jj)::value]; });
     rank1x<M, N, true>(G, Hc, Bcol);
+    SIP_SEG(3);
     const bool gfail = chol_ldl_dpp<M>(G, rinvG, c); // lqr.cpp:696-701
+    SIP_SEG(4);
     if (stat == 0 && gfail)
       stat = 3; // G_FACTORIZATION_FAILURE
 
@@ -421,11 +452,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
           [&](auto jj) { gi[decltype(jj)::value] = K[decltype(jj)::value]; });
     }
 
+    SIP_SEG(5);
     // [V | v] = [Q | q] + A^T [F | g] + K^T [H | h]  (lqr.cpp:715-719,:793-794)
     spreadx<N, N, false>(Vn, Acol, F);
     spreadx<N, M, true>(Vn, K, H);
     sfor<0, N>(
         [&](auto ii) { V[decltype(ii)::value] = Vn[decltype(ii)::value]; });
+    SIP_SEG(6);
   };
 
   // Reads edge i from its stage block (em: edge part of mats, ev: r of vecs).
@@ -471,32 +504,45 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     double Acol[N], Bcol[N], MT[M], Rcol[M];
     double Vn[N], dl, cv[N], dv[N];
     SIP_STAMP(ts_a);
+#ifdef SIP_LQR_STAMPS
+    seg_last = ts_a;
+#endif
     if constexpr (STAGED) {
       lds_char *buf = lds + (i & 1) * C::B_BYTES;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stage i has landed
+      // Stage i has landed.  The N buffer stores of the packed-W spill are the
+      // last vector-memory operations of the previous node (every lane issues
+      // them, out-of-range ones included), so they may stay in flight:
+      // everything older -- this stage's LDS-DMA -- is complete.
+      if constexpr (WPACK)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SIP_STAMP(ts_b);
       acc_bwait += ts_b - ts_a;
-      lds_cdouble *nm = (lds_cdouble *)(buf + rr * (STG * 8));
-      lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + rr * (VSTG * 8));
-      load_edge(nm + L::NODE, nv + L::VNODE, Acol, Bcol, MT, Rcol);
-      load_node(nm, nv, Vn, dl, cv, dv);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all of it in VGPRs
-      if (i > 0) { // next stage streams in behind this stage's arithmetic
+      SIP_SEG(0);
+      if (i > 0) { // next stage streams into the other buffer meanwhile
         lds_char *nbuf = lds + ((i - 1) & 1) * C::B_BYTES;
         dma_bm.issue((const char *)(mats + p0 * mats_len + (long)(i - 1) * STG),
                      nbuf, lane);
         dma_bv.issue(
             (const char *)(vecs + p0 * vecs_len + (long)(i - 1) * VSTG),
             nbuf + C::BM::BYTES, lane);
+        asm volatile("" ::: "memory"); // stores of this stage stay younger
       }
+      lds_cdouble *nm = (lds_cdouble *)(buf + rr * (STG * 8));
+      lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + rr * (VSTG * 8));
+      load_edge(nm + L::NODE, nv + L::VNODE, Acol, Bcol, MT, Rcol);
+      load_node(nm, nv, Vn, dl, cv, dv);
     } else {
       const double *nm = pm + (long)i * STG;
       const double *nv = pv + (long)i * VSTG;
       load_edge(nm + L::NODE, nv + L::VNODE, Acol, Bcol, MT, Rcol);
       load_node(nm, nv, Vn, dl, cv, dv);
     }
+    SIP_SEG(1);
     backward_edge(i, Acol, Bcol, MT, Rcol, Vn);
     finish_node(i, dl, cv, dv);
+    SIP_SEG(9);
   }
 
   SIP_STAMP(ts_bwd);
@@ -663,10 +709,12 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
 #ifdef SIP_LQR_STAMPS
   SIP_STAMP(ts_end);
   if (stamps != nullptr && lane == 0) {
-    unsigned long long *o = stamps + (long)blockIdx.x * 8;
+    unsigned long long *o = stamps + (long)blockIdx.x * 24;
     o[0] = ts_begin, o[1] = ts_term, o[2] = ts_bwd, o[3] = ts_root;
     o[4] = ts_end, o[5] = acc_bwait, o[6] = acc_fwait;
     o[7] = __builtin_amdgcn_s_memrealtime();
+    for (int k = 0; k < 12; ++k)
+      o[8 + k] = seg[k];
   }
 #endif
 }

@@ -15,7 +15,7 @@ mats, vecs = synthetic.make_chain_batch(shape, batch, seed=1, device="cuda:0")
 solver = BatchedChainLQR(n, m, T, batch, device="cuda:0")
 lib = load_library()
 waves = (batch + 3) // 4
-st = torch.zeros(waves * 8, dtype=torch.int64, device="cuda:0")
+st = torch.zeros(waves * 24, dtype=torch.int64, device="cuda:0")
 fn = ctypes.CDLL(os.environ["SIP_LQR_LIB"]).sip_lqr_debug_set_stamps
 fn.argtypes = [ctypes.c_void_p]
 sol = solver.empty_sol(); gains = solver.empty_gains()
@@ -23,7 +23,7 @@ for it in range(5):
     fn(ctypes.c_void_p(st.data_ptr()))
     solver.factor_solve(mats, vecs, sol, gains)
     torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(waves, 8).astype(np.float64)
+s = st.cpu().numpy().reshape(waves, 24).astype(np.float64)
 tot = s[:, 4] - s[:, 0]
 print("kernel:", solver.kernel_name)
 print("waves", waves, "cycles per wave: total median %.0f  min %.0f max %.0f" % (np.median(tot), tot.min(), tot.max()))
@@ -36,3 +36,9 @@ print("  forward loop       %.0f  (per stage %.0f), of which waiting for the sta
 span = (s[:, 4].max() - s[:, 0].min())
 print("  first start -> last end (shader clocks, per-XCD counters may differ): %.0f" % span)
 print("  start skew: %.0f" % (s[:, 0].max() - s[:, 0].min()))
+names = ["wait DMA", "LDS reads + DMA issue", "F = W [A|t] (+g store)", "Hc, G products", "LDL(G)",
+         "H, K solve, gains store", "V += A^T F + K^T H", "status/t/vch", "node_factor (S, LDL F, F^-1, W)",
+         "W store + loop tail", "-", "-"]
+print("  backward segments, cycles per stage (median over waves):")
+for k in range(10):
+    print("    %-36s %7.0f" % (names[k], np.median(s[:, 8 + k]) / T))
