@@ -266,9 +266,13 @@ struct StagedCfg {
 #define SIP_LQR_FNBUF 3
 #endif
   static constexpr int F_NBUF = SIP_LQR_FNBUF; // forward: F_NBUF-1 stages ahead
-  static constexpr int LDS_BYTES = B_NBUF * B_BYTES > F_NBUF * F_BYTES
-                                       ? B_NBUF * B_BYTES
-                                       : F_NBUF * F_BYTES;
+  static constexpr int LDS_MAIN = B_NBUF * B_BYTES > F_NBUF * F_BYTES
+                                      ? B_NBUF * B_BYTES
+                                      : F_NBUF * F_BYTES;
+  // per-row scratch behind the stage buffers: t (N) | v_child (N) of the
+  // vector lane, then one block of N zeros
+  static constexpr int SCR_BYTES = ((4 * 2 * N + N) * 8 + 1023) / 1024 * 1024;
+  static constexpr int LDS_BYTES = LDS_MAIN + SCR_BYTES;
   static constexpr bool OK = (N % 2 == 0) && (M % 2 == 0);
 };
 
@@ -346,34 +350,71 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
                               ? (int)(rr * ws_len * 8) + (c * N - (c * (c - 1)) / 2 - c) * 8
                               : 0x7ffff000;
 
-  // Loads [Q_i | q_i] as the augmented column, delta_i per lane, and on the
-  // vector lane c_i, delta_i as columns.  nm / nv: stage block of mats / vecs.
-  auto load_node = [&](auto nm, auto nv, double(&Vq)[N], double &dl,
-                       double(&cv)[N], double(&dv)[N]) {
+  // STAGED: the vector lane parks t = c - delta o v and v (needed by the
+  // parent step only on that lane) in LDS; every other lane reads zeros there.
+  typedef __attribute__((address_space(3))) double lds_double;
+  lds_char *const scr = lds + C::LDS_MAIN;
+  lds_double *const my_t = (lds_double *)(scr + rr * (2 * N * 8));
+  lds_double *const my_v = my_t + N;
+  lds_cdouble *const zeros = (lds_cdouble *)(scr + 4 * (2 * N * 8));
+  if constexpr (STAGED) {
+    if (lane < N)
+      ((lds_double *)zeros)[lane] = 0.0;
+  }
+
+  // Loads [Q_i | q_i] as the augmented column.  nm / nv: stage block of mats /
+  // vecs (global or LDS).
+  auto load_vq = [&](auto nm, auto nv, double(&Vq)[N]) {
     auto src = isV ? nv : nm + cm * N;
     sfor<0, N>([&](auto ii) {
       constexpr int r = decltype(ii)::value;
       Vq[r] = src[r];
-      cv[r] = nv[N + r];
-      dv[r] = nm[N * N + r];
     });
-    const double d = nm[N * N + cm];
-    dl = isM ? d : 1.0;
   };
 
   // Common tail of every node: statuses, F/W (lqr.cpp:722-727 + 689), the
-  // vector-lane terms for the parent step, and the W spill.
-  auto finish_node = [&](const int i, const double dl, const double(&cv)[N],
-                         const double(&dv)[N]) {
+  // vector-lane terms for the parent step (t = c - delta o v = -f of
+  // lqr.cpp:778-779, and v), and the W spill.
+  // Operands of finish_node, fetched ahead of it: delta_c one per lane, and
+  // (meaningful on the vector lane) c and delta as columns.
+  struct NodeTail {
+    double dl, cv[N], dv[N];
+  };
+  auto load_tail = [&](auto nm, auto nv, NodeTail &nt) {
+    const double d = nm[N * N + cm];
+    nt.dl = isM ? d : 1.0;
+    sfor<0, N>([&](auto ii) {
+      constexpr int r = decltype(ii)::value;
+      nt.cv[r] = nv[N + r];
+      nt.dv[r] = nm[N * N + r];
+    });
+  };
+  auto finish_node = [&](const int i, const NodeTail &nt) {
+    const double dl = nt.dl;
     const unsigned long long bad = __ballot(isM && dl <= 0.0);
     const bool bad_row = ((bad >> (lane & 48)) & 0xffffull) != 0;
     if (stat == 0 && bad_row)
       stat = 1; // INVALID_DELTA
-    sfor<0, N>([&](auto ii) {
-      constexpr int r = decltype(ii)::value;
-      t[r] = cv[r] - dv[r] * V[r]; // -(f) = c - delta o v, lqr.cpp:778-779
-      vch[r] = V[r];
-    });
+    if constexpr (STAGED) {
+      double tv[N];
+      sfor<0, N>([&](auto ii) {
+        constexpr int r = decltype(ii)::value;
+        tv[r] = nt.cv[r] - nt.dv[r] * V[r];
+      });
+      if (isV) {
+        sfor<0, N>([&](auto ii) {
+          constexpr int r = decltype(ii)::value;
+          my_t[r] = tv[r];
+          my_v[r] = V[r];
+        });
+      }
+    } else {
+      sfor<0, N>([&](auto ii) {
+        constexpr int r = decltype(ii)::value;
+        t[r] = nt.cv[r] - nt.dv[r] * V[r];
+        vch[r] = V[r];
+      });
+    }
     SIP_SEG(7);
     const bool ffail = node_factor<N>(V, dl, c, E, W);
     SIP_SEG(8);
@@ -398,36 +439,55 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     }
   };
 
-  // One backward step over edge i (lqr.cpp:660-720 and :746-795), all inputs
-  // already in registers.
-  auto backward_edge = [&](const int i, const double(&Acol)[N],
-                           const double(&Bcol)[N], const double(&MT)[M],
-                           const double(&Rcol)[M], double(&Vn)[N]) {
+  // One backward step over edge i (lqr.cpp:660-720 and :746-795).  nm / nv:
+  // stage block i of mats / vecs (global memory, or its LDS image).  Operands
+  // are fetched one segment ahead of their use (the memory fences keep the
+  // compiler from hoisting all ~140 registers of a stage to the top).
+  auto backward_edge = [&](const int i, auto nm, auto nv, NodeTail &nt) {
+    auto em = nm + L::NODE;
     // [F | g - v_c] = W [A | t]   (lqr.cpp:703 and :780-781)
-    double F[N];
-    sfor<0, N>([&](auto ii) {
-      constexpr int r = decltype(ii)::value;
-      F[r] = isV ? vch[r] : 0.0; // vector lane accumulates g = v_c + W t
-    });
-    double Aaug[N];
-    sfor<0, N>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      Aaug[k] = isV ? t[k] : Acol[k];
-    });
+    double F[N], Aaug[N], Bcol[N];
+    double Hc[M], G[M], rinvG[M], H[M], K[M];
+    {
+      auto msrc = isV ? nv + L::VNODE : em + (N * N + N * M + cm);
+      sfor<0, M>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        G[j] = em[N * N + 2 * N * M + cu * M + j]; // column c of R
+        // column c of M^T = row c of M; vector lane: r
+        H[j] = isV ? msrc[j] : msrc[j * N];
+      });
+    }
+    if constexpr (STAGED) {
+      auto a_src = isV ? (lds_cdouble *)my_t : em + cm * N;
+      auto f_src = isV ? (lds_cdouble *)my_v : zeros;
+      sfor<0, N>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        Aaug[k] = a_src[k]; // vector lane: t
+        F[k] = f_src[k];    // vector lane accumulates g = v_c + W t
+        Bcol[k] = em[N * N + cu * N + k];
+      });
+    } else {
+      sfor<0, N>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        Aaug[k] = isV ? t[k] : em[cm * N + k];
+        F[k] = isV ? vch[k] : 0.0;
+        Bcol[k] = em[N * N + cu * N + k];
+      });
+    }
     rank1x<N, N, true>(F, W, Aaug);
     if (valid && isV) {
       double *gn = pw + (long)(i + 1) * WSN + WG;
       sfor<0, N>(
           [&](auto ii) { gn[decltype(ii)::value] = F[decltype(ii)::value]; });
     }
-
     SIP_SEG(2);
+    asm volatile("" ::: "memory");
+    double Vn[N];
+    load_vq(nm, nv, Vn); // [Q | q]: in flight behind the G / K work
+
     // H_child = B^T W (lqr.cpp:692); G = R + H_child B (lqr.cpp:693-694)
-    double Hc[M], G[M], rinvG[M];
     sfor<0, M>([&](auto jj) { Hc[decltype(jj)::value] = 0.0; });
     spreadx<M, N, false>(Hc, Bcol, W);
-    sfor<0, M>(
-        [&](auto jj) { G[decltype(jj)::value] = Rcol[decltype(jj)::value]; });
     rank1x<M, N, true>(G, Hc, Bcol);
     SIP_SEG(3);
     const bool gfail = chol_ldl_dpp<M>(G, rinvG, c); // lqr.cpp:696-701
@@ -436,10 +496,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       stat = 3; // G_FACTORIZATION_FAILURE
 
     // [H | h] = [M^T | r] + B^T [F | g]   (lqr.cpp:704-705, :783-784)
-    double H[M], K[M];
-    sfor<0, M>(
-        [&](auto jj) { H[decltype(jj)::value] = MT[decltype(jj)::value]; });
     spreadx<M, N, false>(H, Bcol, F);
+    asm volatile("" ::: "memory");
+    load_tail(nm, nv, nt); // c, delta: in flight behind the gain solve
     // [K | k] = -G^{-1} [H | h]   (lqr.cpp:707-713, :785-791)
     sfor<0, M>(
         [&](auto jj) { K[decltype(jj)::value] = H[decltype(jj)::value]; });
@@ -454,28 +513,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
 
     SIP_SEG(5);
     // [V | v] = [Q | q] + A^T [F | g] + K^T [H | h]  (lqr.cpp:715-719,:793-794)
-    spreadx<N, N, false>(Vn, Acol, F);
+    // (Aaug's vector lane is never broadcast: spread reads lanes < N only)
+    spreadx<N, N, false>(Vn, Aaug, F);
     spreadx<N, M, true>(Vn, K, H);
     sfor<0, N>(
         [&](auto ii) { V[decltype(ii)::value] = Vn[decltype(ii)::value]; });
     SIP_SEG(6);
-  };
-
-  // Reads edge i from its stage block (em: edge part of mats, ev: r of vecs).
-  auto load_edge = [&](auto em, auto ev, double(&Acol)[N], double(&Bcol)[N],
-                       double(&MT)[M], double(&Rcol)[M]) {
-    sfor<0, N>([&](auto ii) {
-      constexpr int r = decltype(ii)::value;
-      Acol[r] = em[cm * N + r];
-      Bcol[r] = em[N * N + cu * N + r];
-    });
-    auto msrc = isV ? ev : em + (N * N + N * M + cm);
-    sfor<0, M>([&](auto jj) {
-      constexpr int j = decltype(jj)::value;
-      // column c of M^T = row c of M; vector lane: r
-      MT[j] = isV ? msrc[j] : msrc[j * N];
-      Rcol[j] = em[N * N + 2 * N * M + cu * M + j];
-    });
+    asm volatile("" ::: "memory");
   };
 
   // ---- terminal node (lqr.cpp:651-658 with no child edge) ----------------
@@ -493,16 +537,15 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     }
   }
   {
-    double dl, cv[N], dv[N];
-    load_node(pm + (long)T * STG, pv + (long)T * VSTG, V, dl, cv, dv);
-    finish_node(T, dl, cv, dv);
+    NodeTail nt;
+    load_vq(pm + (long)T * STG, pv + (long)T * VSTG, V);
+    load_tail(pm + (long)T * STG, pv + (long)T * VSTG, nt);
+    finish_node(T, nt);
   }
   SIP_STAMP(ts_term);
 
   // ---- backward recursion over edges i = T-1 .. 0 -------------------------
   for (int i = T - 1; i >= 0; --i) {
-    double Acol[N], Bcol[N], MT[M], Rcol[M];
-    double Vn[N], dl, cv[N], dv[N];
     SIP_STAMP(ts_a);
 #ifdef SIP_LQR_STAMPS
     seg_last = ts_a;
@@ -531,32 +574,39 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       }
       lds_cdouble *nm = (lds_cdouble *)(buf + rr * (STG * 8));
       lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + rr * (VSTG * 8));
-      load_edge(nm + L::NODE, nv + L::VNODE, Acol, Bcol, MT, Rcol);
-      load_node(nm, nv, Vn, dl, cv, dv);
+      SIP_SEG(1);
+      NodeTail nt;
+      backward_edge(i, nm, nv, nt);
+      finish_node(i, nt);
     } else {
       const double *nm = pm + (long)i * STG;
       const double *nv = pv + (long)i * VSTG;
-      load_edge(nm + L::NODE, nv + L::VNODE, Acol, Bcol, MT, Rcol);
-      load_node(nm, nv, Vn, dl, cv, dv);
+      SIP_SEG(1);
+      NodeTail nt;
+      backward_edge(i, nm, nv, nt);
+      finish_node(i, nt);
     }
-    SIP_SEG(1);
-    backward_edge(i, Acol, Bcol, MT, Rcol, Vn);
-    finish_node(i, dl, cv, dv);
     SIP_SEG(9);
   }
 
   SIP_STAMP(ts_bwd);
   // ---- root: g_0 = v_0 + W_0 (c_0 - delta_0 o v_0)  (lqr.cpp:798-819) -----
   {
-    double F[N];
-    sfor<0, N>([&](auto ii) { F[decltype(ii)::value] = 0.0; });
-    rank1x<N, N, true>(F, W, t);
+    double F[N], tt[N];
+    sfor<0, N>([&](auto ii) {
+      constexpr int r = decltype(ii)::value;
+      if constexpr (STAGED) {
+        tt[r] = isV ? my_t[r] : 0.0;
+        F[r] = isV ? my_v[r] : 0.0;
+      } else {
+        tt[r] = t[r];
+        F[r] = vch[r];
+      }
+    });
+    rank1x<N, N, true>(F, W, tt);
     if (valid && isV) {
       double *gn = pw + WG;
-      sfor<0, N>([&](auto ii) {
-        constexpr int r = decltype(ii)::value;
-        gn[r] = F[r] + vch[r];
-      });
+      sfor<0, N>([&](auto ii) { gn[decltype(ii)::value] = F[decltype(ii)::value]; });
     }
   }
   if (valid && c == 0)

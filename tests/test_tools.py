@@ -1,0 +1,67 @@
+"""The static DPP-hazard checker (tools/check_dpp_hazards.py) that guards the
+inline-asm broadcast-FMA blocks: it must flag a VALU write -> DPP read with
+fewer than 2 wait states on any path, and accept padded code."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("chk", os.path.join(ROOT, "tools", "check_dpp_hazards.py"))
+chk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(chk)
+
+DPP = "v_fmac_f64_dpp v[10:11], v[2:3], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf"
+
+
+def _probs(text):
+    return chk.check(chk.parse_kernel(text.strip().split("\n")), "k")
+
+
+def test_flags_back_to_back_write_then_dpp_read():
+    assert len(_probs(f"\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\t{DPP}")) == 1
+    assert len(_probs(f"\tv_accvgpr_read_b32 v3, a7\n\tv_mov_b32_e32 v40, v41\n\t{DPP}")) == 1
+
+
+def test_accepts_two_wait_states():
+    assert _probs(f"\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\ts_nop 1\n\t{DPP}") == []
+    assert _probs(f"\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\tv_mov_b32_e32 v40, v41\n\ts_nop 0\n\t{DPP}") == []
+    # one s_nop 0 is a single wait state: still a hazard
+    assert len(_probs(f"\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\ts_nop 0\n\t{DPP}")) == 1
+
+
+def test_ignores_non_valu_writers_and_other_registers():
+    assert _probs(f"\tds_read_b64 v[2:3], v9\n\t{DPP}") == []
+    assert _probs(f"\tglobal_load_dwordx2 v[2:3], v[20:21], off\n\t{DPP}") == []
+    assert _probs(f"\tv_mul_f64 v[4:5], v[6:7], v[8:9]\n\t{DPP}") == []      # src1, not the DPP source
+
+
+def test_follows_branches_into_labels():
+    text = f"""
+\tv_mul_f64 v[2:3], v[6:7], v[8:9]
+\ts_cbranch_scc1 .LBB0_5
+\ts_nop 4
+\ts_nop 4
+.LBB0_5:
+\t{DPP}
+"""
+    assert len(_probs(text)) == 1          # via the taken branch: only one wait state
+
+
+def test_flags_vcmpx_exec_write():
+    assert len(_probs(f"\tv_cmpx_gt_u32_e32 v1, v2\n\ts_nop 1\n\t{DPP}")) == 1
+
+
+def test_shipped_kernels_are_hazard_free():
+    """Rebuild the device assembly and check every kernel of the library."""
+    import subprocess
+    import tempfile
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               os.path.join(ROOT, "sip_optimal_control_amd", "csrc", "sip_lqr_amd.hip"),
+                               "-o", os.path.join(tmp, "k.s")])
+        rc = subprocess.call(["python3", os.path.join(ROOT, "tools", "check_dpp_hazards.py"),
+                              os.path.join(tmp, "k.s"), "chain_factor_solve"])
+    assert rc == 0
