@@ -1,0 +1,405 @@
+// chain_mf32.hpp -- fp32 batched chain Riccati kernel for n = 32 on the matrix
+// cores (BASELINE config 4: batch 4096, T = 100, n = 32, m = 8).
+//
+// One problem per wavefront.  Every 32 x 32 (and m x 32) matrix lives in
+// registers in the C/D layout of v_mfma_f32_32x32x2_f32 -- lane (j, h), reg p
+// holds element (row r(p,h) = (p & 3) + 8 (p >> 2) + 4 h, column j) -- because
+// in that layout the matrix pipe computes transposed products for free:
+//
+//      sum_p  mfma_32x32x2( U[p], V[p] )  =  U^T V          (again in C/D layout)
+//
+// (each MFMA consumes the row pair r(p,0), r(p,1) of both factors as its K = 2
+// slice).  Every product of the backward recursion is of that shape:
+//      F = W A   = W^T A  (W symmetric)        lqr.cpp:703
+//      Z = W B   = W^T B                       (H_child^T of lqr.cpp:692)
+//      G = R + B^T Z                           lqr.cpp:693-694
+//      H = M^T + B^T F                         lqr.cpp:704-705
+//      V = Q + A^T F + K^T H                   lqr.cpp:715-719
+//      F^-1 = X^T X with X = L^-1              (the two solves of lqr.cpp:516-519)
+// so no operand ever goes through LDS.  Cholesky / the triangular inverse run
+// on the VALU, one matrix row (resp. inverse column) per lane, with
+// v_readlane as the broadcast (uniform: the whole wave works on one problem);
+// both 32-lane halves compute them redundantly so that the result can be
+// re-read in either half of the C/D layout.  Vectors (g, h, k, v of the affine
+// sweep, x, u, y of the rollout) are small LDS arrays.
+//
+// Arithmetic is IEEE fp32 (MFMA f32: exact fmaf chains); parity with the fp64
+// oracle is judged by the KKT residual (tests/test_gpu_general_chain.py).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sipamd {
+namespace mf32 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int N = 32;
+
+__device__ __forceinline__ int crow(const int p, const int h) {
+  return (p & 3) + 8 * (p >> 2) + 4 * h;
+}
+
+// acc += U^T V  (all three in C/D layout); ROWS: rows of U / V that can be
+// nonzero (32, or 8 for the m-row factors, whose rows live in regs 0..3).
+template <int ROWS>
+__device__ __forceinline__ void prodT(const f32x16 &U, const f32x16 &V, f32x16 &acc) {
+  constexpr int P = ROWS == 32 ? 16 : 4;
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(U[p], V[p], acc, 0, 0, 0);
+}
+
+// Column-major (ld = rows) global matrix -> C/D layout.  Columns >= cols read
+// as zero.  32-row matrices: four 16-byte loads per lane.
+__device__ __forceinline__ f32x16 load_c32(const float *m, const int cols, const int j, const int h) {
+  f32x16 r;
+  const f32x4 *src = (const f32x4 *)(m + (j < cols ? j : 0) * N + 4 * h);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v = src[2 * g];
+    if (j >= cols)
+      v = f32x4{0.f, 0.f, 0.f, 0.f};
+    r[4 * g + 0] = v[0], r[4 * g + 1] = v[1], r[4 * g + 2] = v[2], r[4 * g + 3] = v[3];
+  }
+  return r;
+}
+
+// y_j = sum_r Mc[r][j] * vec[r]  for the column j of this lane (both halves get
+// the full sum).  vec: LDS array indexed by row.
+__device__ __forceinline__ float matTvec(const f32x16 &Mc, const float *vec, const int h) {
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+    s = __builtin_fmaf(Mc[p], vec[crow(p, h)], s);
+  return s + __shfl_xor(s, 32);
+}
+
+template <int M>
+struct Layout {
+  static constexpr int NODE = N * N + N;               // Q | delta
+  static constexpr int EDGE = N * N + 2 * N * M + M * M; // A | B | M | R
+  static constexpr int VNODE = 2 * N, VEDGE = M, GAIN = M * N + M;
+  static constexpr int WSN = N * N + N; // W (C/D-layout dump) | g
+};
+
+template <int M>
+__global__ __launch_bounds__(64) void chain_factor_solve_mf32(
+    const float *__restrict__ mats, const float *__restrict__ vecs, float *__restrict__ sol,
+    float *__restrict__ gains, float *__restrict__ wsp, int *__restrict__ status, const long batch,
+    const int T) {
+  static_assert(M >= 1 && M <= 8, "control rows must fit regs 0..3 of both halves");
+  using L = Layout<M>;
+  constexpr int STG = L::NODE + L::EDGE, VSTG = L::VNODE + L::VEDGE;
+  const long p = blockIdx.x;
+  if (p >= batch)
+    return;
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const float *pm = mats + p * ((long)(T + 1) * L::NODE + (long)T * L::EDGE);
+  const float *pv = vecs + p * ((long)(T + 1) * L::VNODE + (long)T * L::VEDGE);
+  float *ps = sol + p * ((long)(T + 1) * L::VNODE + (long)T * L::VEDGE);
+  float *pg = gains + p * ((long)T * L::GAIN);
+  float *pw = wsp + p * ((long)(T + 1) * L::WSN);
+
+  __shared__ float s_v[N], s_t[N], s_g[N], s_sdi[N], s_h[8], s_k[8], s_x[N], s_z[N], s_u[8];
+  __shared__ float s_G[8 * 8];
+
+  int stat = 0;
+  f32x16 W, V;
+
+  // ---- node tail: F = I + D^1/2 V D^1/2, Cholesky, W (lqr.cpp:487-529, 722-727)
+  // plus the vector terms t = c - delta o v and v for the parent step.
+  auto finish_node = [&](const int i) {
+    const float *nm = pm + (long)i * STG;
+    const float *nv = pv + (long)i * VSTG;
+    const float dl = nm[N * N + j];
+    if (stat == 0 && __any(dl <= 0.f))
+      stat = 1; // INVALID_DELTA
+    const float sd = sqrtf(dl), sdi = 1.f / sd;
+    if (h == 0) {
+      s_sdi[j] = sdi;
+      s_x[j] = sd; // scratch: sqrt_delta by row
+      const float vj = s_v[j];
+      s_t[j] = nv[N + j] - dl * vj; // c - delta o v   (lqr.cpp:778-779, negated)
+    }
+    __syncthreads();
+    // row-per-lane copy of F = I + sd V sd: lane l holds row (l & 31)
+    float a[N];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float own = V[q] * s_x[crow(q, h)] * sd + (crow(q, h) == j ? 1.f : 0.f);
+      const float other = __shfl_xor(own, 32);
+      a[crow(q, 0)] = h == 0 ? own : other; // symmetric: column j == row j
+      a[crow(q, 1)] = h == 0 ? other : own;
+    }
+    // right-looking Cholesky, rows in registers, v_readlane broadcasts
+    bool fail = false;
+    float rinv[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[k]), k));
+      fail |= (d <= 0.f);
+      const float ri = 1.f / sqrtf(d);
+      rinv[k] = ri;
+      a[k] *= ri; // L(i,k), rows i >= k (row k: sqrt(d))
+#pragma unroll
+      for (int c2 = k + 1; c2 < N; ++c2) {
+        const float ljk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[k]), c2));
+        a[c2] = __builtin_fmaf(-a[k], ljk, a[c2]);
+      }
+    }
+    if (stat == 0 && fail)
+      stat = 2; // F_FACTORIZATION_FAILURE
+    // X = L^-1: lane l computes column (l & 31) by forward substitution
+    float x[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      float s = r == j ? 1.f : 0.f;
+#pragma unroll
+      for (int c2 = 0; c2 < r; ++c2) {
+        const float lrc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[c2]), r));
+        s = __builtin_fmaf(-lrc, x[c2], s);
+      }
+      x[r] = s * rinv[r];
+    }
+    // F^-1 = X^T X on the matrix pipe, then W = D^-1/2 (I - F^-1) D^-1/2
+    f32x16 Xc, Finv;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      Xc[q] = h == 0 ? x[crow(q, 0)] : x[crow(q, 1)];
+      Finv[q] = 0.f;
+    }
+    prodT<32>(Xc, Xc, Finv);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = crow(q, h);
+      W[q] = ((r == j ? 1.f : 0.f) - Finv[q]) * (s_sdi[r] * sdi);
+    }
+    // spill W (C/D-layout dump) for the rollout
+    f32x4 *wd = (f32x4 *)(pw + (long)i * L::WSN);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      wd[g * 64 + lane] = f32x4{W[4 * g], W[4 * g + 1], W[4 * g + 2], W[4 * g + 3]};
+    __syncthreads();
+  };
+
+  // ---- terminal node -------------------------------------------------------
+  V = load_c32(pm + (long)T * STG, N, j, h);
+  if (h == 0)
+    s_v[j] = pv[(long)T * VSTG + j]; // v = q
+  __syncthreads();
+  finish_node(T);
+
+  // ---- backward recursion --------------------------------------------------
+  for (int i = T - 1; i >= 0; --i) {
+    const float *nm = pm + (long)i * STG;
+    const float *em = nm + L::NODE;
+    const float *nv = pv + (long)i * VSTG;
+    const f32x16 A = load_c32(em, N, j, h);
+    const f32x16 B = load_c32(em + N * N, M, j, h); // columns >= M are zero
+    // g = v_c + W t   (lqr.cpp:778-781)
+    {
+      const float wt = matTvec(W, s_t, h);
+      if (h == 0) {
+        const float g = s_v[j] + wt;
+        s_g[j] = g;
+        pw[(long)(i + 1) * L::WSN + N * N + j] = g;
+      }
+    }
+    f32x16 F, Z, G, H;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      F[q] = 0.f, Z[q] = 0.f;
+    prodT<32>(W, A, F); // F = W A
+    prodT<32>(W, B, Z); // Z = W B   (H_child^T)
+    // G = R + B^T Z ; H = M^T + B^T F   (rows < M: regs 0..3)
+    const float *Mm = em + N * N + N * M, *Rm = Mm + N * M;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = q + 4 * h; // row of a (<= 8)-row tile for q < 4
+      G[q] = (q < 4 && r < M && j < M) ? Rm[j * M + r] : 0.f;
+      H[q] = (q < 4 && r < M) ? Mm[r * N + j] : 0.f; // M^T(r, j) = M(j, r)
+    }
+    prodT<32>(B, Z, G);
+    prodT<32>(B, F, H);
+    __syncthreads();
+    // h = r + B^T g  (lqr.cpp:783-784): value for control row j on lanes j < M
+    {
+      const float bg = matTvec(B, s_g, h);
+      if (lane < M)
+        s_h[lane] = nv[L::VNODE + lane] + bg;
+      // G to LDS (row r, col c at c * 8 + r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j < M && q + 4 * h < M)
+          s_G[j * 8 + q + 4 * h] = G[q];
+    }
+    __syncthreads();
+    // Cholesky of G (m x m) redundantly in every lane; K = -G^-1 H per column
+    float Lg[8][8], ri[8];
+    bool gfail = false;
+#pragma unroll
+    for (int c2 = 0; c2 < M; ++c2)
+#pragma unroll
+      for (int r = c2; r < M; ++r)
+        Lg[r][c2] = s_G[c2 * 8 + r]; // lower triangle (Eigen reads only it)
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      float d = Lg[k][k];
+#pragma unroll
+      for (int c2 = 0; c2 < k; ++c2)
+        d = __builtin_fmaf(-Lg[k][c2], Lg[k][c2], d);
+      gfail |= (d <= 0.f);
+      const float r1 = 1.f / sqrtf(d);
+      ri[k] = r1;
+#pragma unroll
+      for (int r = k + 1; r < M; ++r) {
+        float s = Lg[r][k];
+#pragma unroll
+        for (int c2 = 0; c2 < k; ++c2)
+          s = __builtin_fmaf(-Lg[r][c2], Lg[k][c2], s);
+        Lg[r][k] = s * r1;
+      }
+    }
+    if (stat == 0 && gfail)
+      stat = 3; // G_FACTORIZATION_FAILURE
+    auto g_solve = [&](float(&y)[8]) { // y <- -(L L^T)^-1 y
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        float s = y[r];
+#pragma unroll
+        for (int c2 = 0; c2 < r; ++c2)
+          s = __builtin_fmaf(-Lg[r][c2], y[c2], s);
+        y[r] = s * ri[r];
+      }
+#pragma unroll
+      for (int r = M - 1; r >= 0; --r) {
+        float s = y[r];
+#pragma unroll
+        for (int c2 = r + 1; c2 < M; ++c2)
+          s = __builtin_fmaf(-Lg[c2][r], y[c2], s);
+        y[r] = s * ri[r];
+      }
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+        y[r] = -y[r];
+    };
+    float Kc[8], kv[8], Hc8[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { // column j of H: rows q (h = 0) and q + 4 (h = 1)
+      const float own = H[q], other = __shfl_xor(own, 32);
+      Hc8[q] = h == 0 ? own : other;
+      Hc8[q + 4] = h == 0 ? other : own;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      Kc[r] = r < M ? Hc8[r] : 0.f;
+      kv[r] = r < M ? s_h[r] : 0.f;
+    }
+    g_solve(Kc); // [K | k] = -G^-1 [H | h]   (lqr.cpp:707-713, 785-791)
+    g_solve(kv);
+    // gains out: K (m x 32 col-major) | k
+    if (h == 0) {
+      float *gi = pg + (long)i * L::GAIN + j * M;
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+        gi[r] = Kc[r];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+        pg[(long)i * L::GAIN + M * N + r] = kv[r];
+    }
+    // v = q + A^T g + K^T h   (lqr.cpp:793-794)
+    {
+      float vn = nv[j] + matTvec(A, s_g, h);
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+        vn = __builtin_fmaf(Kc[r], s_h[r], vn);
+      __syncthreads(); // everyone is done with s_v / s_t / s_g of the child
+      if (h == 0)
+        s_v[j] = vn;
+    }
+    // V = Q + A^T F + K^T H   (lqr.cpp:715-719)
+    f32x16 Kt;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      Kt[q] = q < 4 ? (h == 0 ? Kc[q] : Kc[q + 4]) : 0.f;
+    V = load_c32(nm, N, j, h);
+    prodT<32>(A, F, V);
+    prodT<8>(Kt, H, V);
+    __syncthreads();
+    finish_node(i);
+  }
+
+  // ---- root: g_0 = v_0 + W_0 t_0 ; x_0 = c_0 - delta_0 o g_0, y_0 = g_0 -------
+  {
+    const float wt = matTvec(W, s_t, h);
+    if (h == 0) {
+      const float g = s_v[j] + wt;
+      const float xx = pv[N + j] - pm[N * N + j] * g;
+      ps[j] = xx;
+      ps[N + j] = g;
+      s_x[j] = xx;
+    }
+  }
+  if (lane == 0)
+    status[p] = stat;
+  __syncthreads();
+
+  // ---- forward rollout (lqr.cpp:821-870) -------------------------------------
+  for (int i = 0; i < T; ++i) {
+    const float *em = pm + (long)i * STG + L::NODE;
+    const float *nm1 = pm + (long)(i + 1) * STG;
+    const float *nv1 = pv + (long)(i + 1) * VSTG;
+    const float *gi = pg + (long)i * L::GAIN;
+    const float *wn = pw + (long)(i + 1) * L::WSN;
+    // u = k + K x : lane j < M owns control row j; K(j, r) at r * M + j
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        s = __builtin_fmaf(j < M ? gi[crow(q, h) * M + j] : 0.f, s_x[crow(q, h)], s);
+      s += __shfl_xor(s, 32);
+      if (lane < M)
+        s_u[lane] = gi[M * N + lane] + s;
+    }
+    __syncthreads();
+    // z = A x + B u : lane j owns state row j; A(j, r) at r * 32 + j
+    float z = 0.f;
+    {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        z = __builtin_fmaf(em[crow(q, h) * N + j], s_x[crow(q, h)], z);
+      z += __shfl_xor(z, 32);
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+        z = __builtin_fmaf(em[N * N + r * N + j], s_u[r], z);
+    }
+    if (h == 0)
+      s_z[j] = z;
+    __syncthreads();
+    // y_c = g_c + W_c z ; x_c = z + c_c - delta_c o y_c
+    f32x16 Wc;
+    const f32x4 *wd = (const f32x4 *)wn;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v4 = wd[g * 64 + lane];
+      Wc[4 * g] = v4[0], Wc[4 * g + 1] = v4[1], Wc[4 * g + 2] = v4[2], Wc[4 * g + 3] = v4[3];
+    }
+    const float y = wn[N * N + j] + matTvec(Wc, s_z, h);
+    const float xn = z + (nv1[N + j] - nm1[N * N + j] * y);
+    float *si = ps + (long)i * VSTG;
+    if (lane < M)
+      si[2 * N + lane] = s_u[lane];
+    __syncthreads();
+    if (h == 0) {
+      si[VSTG + j] = xn;
+      si[VSTG + N + j] = y;
+      s_x[j] = xn;
+    }
+    __syncthreads();
+  }
+}
+
+} // namespace mf32
+} // namespace sipamd

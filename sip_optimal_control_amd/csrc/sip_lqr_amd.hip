@@ -13,6 +13,7 @@
 
 #include <memory>
 
+#include "chain_mf32.hpp"
 #include "chain_qw16.hpp"
 #include "generic_plan.hpp"
 
@@ -68,6 +69,15 @@ hipError_t launch_qw16(const sip_lqr_plan *pl, const void *mats,
   return hipGetLastError();
 }
 
+template <int M>
+hipError_t launch_mf32(const sip_lqr_plan *pl, const void *mats, const void *vecs, void *sol, void *gains,
+                       int32_t *status, void *ws, hipStream_t stream) {
+  hipLaunchKernelGGL((sipamd::mf32::chain_factor_solve_mf32<M>), dim3((unsigned)pl->batch), dim3(64), 0,
+                     stream, (const float *)mats, (const float *)vecs, (float *)sol, (float *)gains,
+                     (float *)ws, (int *)status, (long)pl->batch, pl->T);
+  return hipGetLastError();
+}
+
 struct KernelEntry {
   int dtype, n, m;
   const char *name;
@@ -87,8 +97,13 @@ struct KernelEntry {
 
 // First match wins; SIP_LQR_VARIANT=direct|staged (tests, A/B timing) narrows
 // the search to kernels whose name carries that tag.
+// fp32, n = 32: one problem per wavefront, products on the matrix cores
+#define MF32(M)                                                                \
+  { SIP_LQR_F32, 32, M, "chain_factor_solve_mf32<32," #M ",mfma>/f32",          \
+    sipamd::mf32::Layout<M>::WSN, &launch_mf32<M> }
+
 const KernelEntry kKernels[] = {
-    QW16_STAGED(12, 4), QW16_STAGED(4, 2), QW16_DIRECT(12, 4),
+    MF32(8), QW16_STAGED(12, 4), QW16_STAGED(4, 2), QW16_DIRECT(12, 4),
     QW16_DIRECT(4, 2),  QW16_DIRECT(1, 1), QW16_DIRECT(2, 1),
     QW16_DIRECT(3, 2),  QW16_DIRECT(8, 3),
 };
