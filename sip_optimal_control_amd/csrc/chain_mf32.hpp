@@ -16,12 +16,10 @@
 //      H = M^T + B^T F                         lqr.cpp:704-705
 //      V = Q + A^T F + K^T H                   lqr.cpp:715-719
 //      F^-1 = X^T X with X = L^-1              (the two solves of lqr.cpp:516-519)
-// so no operand ever goes through LDS.  Cholesky / the triangular inverse run
-// on the VALU, one matrix row (resp. inverse column) per lane, with
-// v_readlane as the broadcast (uniform: the whole wave works on one problem);
-// both 32-lane halves compute them redundantly so that the result can be
-// re-read in either half of the C/D layout.  Vectors (g, h, k, v of the affine
-// sweep, x, u, y of the rollout) are small LDS arrays.
+// so no operand ever goes through LDS.  The Cholesky of F and the triangular
+// inverse run on the matrix pipe too, two columns per step, as rank-2
+// eliminations (see finish_node).  Vectors (g, h, k, v of the affine sweep,
+// x, u, y of the rollout) are small LDS arrays.
 //
 // Arithmetic is IEEE fp32 (MFMA f32: exact fmaf chains); parity with the fp64
 // oracle is judged by the KKT residual (tests/test_gpu_general_chain.py).
@@ -122,52 +120,68 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mf32(
       s_t[j] = nv[N + j] - dl * vj; // c - delta o v   (lqr.cpp:778-779, negated)
     }
     __syncthreads();
-    // row-per-lane copy of F = I + sd V sd: lane l holds row (l & 31)
-    float a[N];
+    // F = I + sd V sd in C/D layout (lqr.cpp:497-503)
+    f32x16 Acc, Xc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const float own = V[q] * s_x[crow(q, h)] * sd + (crow(q, h) == j ? 1.f : 0.f);
-      const float other = __shfl_xor(own, 32);
-      a[crow(q, 0)] = h == 0 ? own : other; // symmetric: column j == row j
-      a[crow(q, 1)] = h == 0 ? other : own;
+      const bool diag = crow(q, h) == j;
+      Acc[q] = V[q] * s_x[crow(q, h)] * sd + (diag ? 1.f : 0.f);
+      Xc[q] = diag ? 1.f : 0.f; // becomes X = L^-1
     }
-    // right-looking Cholesky, rows in registers, v_readlane broadcasts
+    // Cholesky (Eigen::LLT, lqr.cpp:505) and the triangular inverse together,
+    // two columns per step, as rank-2 eliminations on the matrix pipe: with
+    // [l_k l_k1] the two new columns of L (one entry per lane, by row),
+    //     A <- A - l_k l_k^T - l_k1 l_k1^T            (trailing update)
+    //     X <- X - l_k y_k^T - l_k1 y_k1^T, rows > k1   (forward substitution
+    //                                                  on the identity)
+    // where y_k, y_k1 are the finished rows k, k1 of X = L^-1.  Row k of the
+    // symmetric A (= its column k) sits across the lanes of half h_k in reg
+    // p_k.  Pivots are those of the unblocked Cholesky (a_kk - |L_k,0:k|^2), so
+    // "pivot <= 0" is detected as Eigen does.
     bool fail = false;
-    float rinv[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[k]), k));
-      fail |= (d <= 0.f);
-      const float ri = 1.f / sqrtf(d);
-      rinv[k] = ri;
-      a[k] *= ri; // L(i,k), rows i >= k (row k: sqrt(d))
-#pragma unroll
-      for (int c2 = k + 1; c2 < N; ++c2) {
-        const float ljk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[k]), c2));
-        a[c2] = __builtin_fmaf(-a[k], ljk, a[c2]);
+    for (int pp = 0; pp < 16; ++pp) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int k = 2 * pp, k1 = k + 1;
+      const int hk = (k >> 2) & 1, pk = (k & 3) + 4 * (k >> 3);
+      const float r0 = Acc[pk], r1 = Acc[pk + 1], x0 = Xc[pk], x1 = Xc[pk + 1];
+      const float r0o = __shfl_xor(r0, 32), r1o = __shfl_xor(r1, 32);
+      const float x0o = __shfl_xor(x0, 32), x1o = __shfl_xor(x1, 32);
+      const float rk = h == hk ? r0 : r0o, rk1 = h == hk ? r1 : r1o; // rows k, k1 of A, by column j
+      const float xk = h == hk ? x0 : x0o, xk1 = h == hk ? x1 : x1o; // rows k, k1 of X
+      const float akk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk), k));
+      const float ak1k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk1), k));
+      const float ak1k1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk1), k1));
+      fail |= (akk <= 0.f);
+      const float i11 = __builtin_amdgcn_rsqf(akk); // 1 / L(k,k)
+      const float l21 = ak1k * i11;
+      const float d2 = __builtin_fmaf(-l21, l21, ak1k1);
+      fail |= (d2 <= 0.f);
+      const float i22 = __builtin_amdgcn_rsqf(d2);
+      float lk = rk * i11;                                   // L(j, k)
+      float lk1 = __builtin_fmaf(-l21, lk, rk1) * i22;       // L(j, k1)
+      lk = j >= k ? lk : 0.f;
+      lk1 = j >= k1 ? lk1 : 0.f;
+      const float yk = xk * i11;                             // row k of L^-1
+      const float yk1 = __builtin_fmaf(-l21, yk, xk1) * i22; // row k1
+      if (h == hk) {
+        Xc[pk] = yk;
+        Xc[pk + 1] = yk1;
       }
+      const float xa = h == 0 ? lk : lk1;
+      const float xm = j > k1 ? xa : 0.f; // rows <= k1 of X are final
+      const float yb = h == 0 ? yk : yk1;
+      Acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-xa, xa, Acc, 0, 0, 0);
+      Xc = __builtin_amdgcn_mfma_f32_32x32x2f32(-xm, yb, Xc, 0, 0, 0);
     }
     if (stat == 0 && fail)
       stat = 2; // F_FACTORIZATION_FAILURE
-    // X = L^-1: lane l computes column (l & 31) by forward substitution
-    float x[N];
-#pragma unroll
-    for (int r = 0; r < N; ++r) {
-      float s = r == j ? 1.f : 0.f;
-#pragma unroll
-      for (int c2 = 0; c2 < r; ++c2) {
-        const float lrc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[c2]), r));
-        s = __builtin_fmaf(-lrc, x[c2], s);
-      }
-      x[r] = s * rinv[r];
-    }
     // F^-1 = X^T X on the matrix pipe, then W = D^-1/2 (I - F^-1) D^-1/2
-    f32x16 Xc, Finv;
+    f32x16 Finv;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      Xc[q] = h == 0 ? x[crow(q, 0)] : x[crow(q, 1)];
+    for (int q = 0; q < 16; ++q)
       Finv[q] = 0.f;
-    }
     prodT<32>(Xc, Xc, Finv);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
