@@ -52,6 +52,9 @@ def main():
     fetch, kname = counters(os.path.join(src, "fetch"), key)
     write, _ = counters(os.path.join(src, "write"), key)
     sq, _ = counters(os.path.join(src, "sq"), key)
+    mfma, _ = counters(os.path.join(src, "mfma"), key)
+    for k2, v2 in mfma.items():
+        sq.setdefault(k2 if k2 != "GRBM_GUI_ACTIVE" else "GRBM_GUI_ACTIVE (mfma pass)", v2)
     fetch_kib = fetch.get("FETCH_SIZE", (0, 0))[0]
     write_kib = write.get("WRITE_SIZE", (0, 0))[0]
     hbm = (2.0 * fetch_kib + write_kib) * 1024.0
@@ -89,6 +92,13 @@ def main():
             f.write(f"| traffic / algorithmic | {hbm/alg:.2f} |\n")
         for k in sorted(sq):
             f.write(f"| {k} (mean/launch) | {sq[k][0]:.4g} |\n")
+        if sq.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[0] > 0 and "GRBM_GUI_ACTIVE" in sq:
+            # matrix-pipe cycles (64 per v_mfma_f32_32x32x2_f32) over all SIMD-cycles of the launch:
+            # GRBM_GUI_ACTIVE sums the 8 XCDs, 1024 SIMDs on the chip
+            util = sq["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (sq["GRBM_GUI_ACTIVE"][0] / 8.0 * 1024.0)
+            f.write(f"| MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) | {util:.3f} |\n")
+            flops = sq.get("SQ_INSTS_MFMA", (0, 0))[0] * 32 * 32 * 2 * 2
+            f.write(f"| MFMA flop/s (f32 32x32x2: 4096 flop each) | {flops / (float(krow['AverageNs']) * 1e-9) / 1e12:.1f} TFLOP/s of 157.3 peak |\n")
         if "GRBM_GUI_ACTIVE" in sq:
             clk = sq["GRBM_GUI_ACTIVE"][0] / 8.0 / (float(krow["AverageNs"]) * 1e-9) / 1e9
             f.write(f"| effective clock = GRBM_GUI_ACTIVE / 8 / duration | {clk:.2f} GHz |\n")
