@@ -110,10 +110,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py ...`")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; (modulo only matters for rehearsals with more ranks than GPUs)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("SIP_LQR_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:  # rehearsal of the N > 1 control flow on a box without N GPUs
+            dist.init_process_group(backend)
 
     batch, T, n, m, dt = WORKLOADS[args.workload]
     if args.batch:

@@ -59,7 +59,13 @@ class GainsAllGather:
         if self.world == 1:
             self.gathered[s].copy_(self.local[s])
             return self.gathered[s]
-        if self.on_gpu:
+        if self.on_gpu and dist.get_backend(self.group) != "nccl":
+            # rehearsal backends (gloo) take host tensors: stage through the CPU, synchronously
+            torch.cuda.current_stream(self.device).synchronize()
+            host = torch.empty(self.gathered[s].shape, dtype=self.gathered[s].dtype)
+            dist.all_gather_into_tensor(host, self.local[s].cpu(), group=self.group)
+            self.gathered[s].copy_(host)
+        elif self.on_gpu:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):

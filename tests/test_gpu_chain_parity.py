@@ -58,3 +58,44 @@ def test_kkt_residual_full_size(oracle_lib):
         x, u, y = dense_kkt.chain_sol_from_packed(n, m, T, sol[p])
         worst = max(worst, dense_kkt.residual_norm(par, ch, [n] * (T + 1), [m] * T, b, x, u, y))
     assert worst < 1e-9, worst
+
+
+def test_full_size_linearity_and_idempotence():
+    """Size-independent properties at BASELINE C3 (batch 4096): the solution is
+    linear in the right-hand side (q, r, c): sol(a*vecs1 + vecs2) = a*sol(vecs1) + sol(vecs2);
+    gains' K part does not depend on it; a second identical launch is bitwise identical."""
+    from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
+    n, m, T, batch = 12, 4, 50, 4096
+    shape = ChainShape(n, m, T)
+    mats, v1 = synthetic.make_chain_batch(shape, batch, seed=31, device="cuda:0")
+    _, v2 = synthetic.make_chain_batch(shape, batch, seed=32, device="cuda:0")
+    solver = BatchedChainLQR(n, m, T, batch)
+    s1, g1, st = solver.factor_solve(mats, v1)
+    s1, g1 = s1.clone(), g1.clone()
+    assert bool((st == 0).all())
+    s1b, g1b, _ = solver.factor_solve(mats, v1)
+    assert torch.equal(s1, s1b) and torch.equal(g1, g1b)          # idempotent, deterministic
+    s2 = solver.factor_solve(mats, v2)[0].clone()
+    g2 = solver.empty_gains()
+    s3 = solver.factor_solve(mats, (2.5 * v1 + v2).contiguous(), gains=g2)[0]
+    torch.cuda.synchronize()
+    scale = s3.abs().amax(dim=1, keepdim=True)
+    assert float(((s3 - (2.5 * s1 + s2)).abs() / scale).max()) < 1e-9
+    K1 = g1.view(batch, T, shape.gain)[:, :, :m * n]
+    K2 = g2.view(batch, T, shape.gain)[:, :, :m * n]
+    assert torch.equal(K1, K2)                                      # K depends on mats only
+
+
+def test_empty_horizon_and_single_problem():
+    """T = 0 (root only) and batch = 1 edge cases through the fused kernel."""
+    from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
+    from oracle import oracle
+    for (n, m, T, batch) in [(12, 4, 0, 1), (4, 2, 0, 5), (12, 4, 1, 1)]:
+        shape = ChainShape(n, m, T)
+        mats, vecs = synthetic.make_chain_batch(shape, batch, seed=5, device="cuda:0")
+        solver = BatchedChainLQR(n, m, T, batch)
+        sol, gains, status = solver.factor_solve(mats, vecs)
+        torch.cuda.synchronize()
+        ref_sol, _, ref_status = oracle.chain_batch(n, m, T, mats.cpu().numpy(), vecs.cpu().numpy())
+        np.testing.assert_array_equal(status.cpu().numpy(), ref_status)
+        assert _rel(sol.cpu().numpy(), ref_sol) <= TOL
