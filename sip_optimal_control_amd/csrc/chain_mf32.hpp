@@ -72,6 +72,57 @@ __device__ __forceinline__ float matTvec(const f32x16 &Mc, const float *vec, con
   return s + __shfl_xor(s, 32);
 }
 
+// Cholesky (Eigen::LLT, lqr.cpp:505 / :697) and the triangular inverse together,
+// two columns per step, as rank-2 eliminations on the matrix pipe: with
+// [l_k l_k1] the two new columns of L (one entry per lane, by row),
+//     A <- A - l_k l_k^T - l_k1 l_k1^T            (trailing update)
+//     X <- X - l_k y_k^T - l_k1 y_k1^T, rows > k1   (forward substitution
+//                                                  on the identity)
+// where y_k, y_k1 are the finished rows k, k1 of X = L^-1.  Row k of the
+// symmetric A (= its column k) sits across the lanes of half h_k in reg p_k.
+// Pivots are those of the unblocked Cholesky (a_kk - |L_k,0:k|^2), so
+// "pivot <= 0" is detected as Eigen does.  PANELS = order / 2; on entry X = I.
+// Returns true iff a pivot was <= 0.
+template <int PANELS>
+__device__ __forceinline__ bool eliminate(f32x16 &Acc, f32x16 &Xc, const int j, const int h) {
+  bool fail = false;
+#pragma unroll
+  for (int pp = 0; pp < PANELS; ++pp) {
+    const int k = 2 * pp, k1 = k + 1;
+    const int hk = (k >> 2) & 1, pk = (k & 3) + 4 * (k >> 3);
+    const float r0 = Acc[pk], r1 = Acc[pk + 1], x0 = Xc[pk], x1 = Xc[pk + 1];
+    const float r0o = __shfl_xor(r0, 32), r1o = __shfl_xor(r1, 32);
+    const float x0o = __shfl_xor(x0, 32), x1o = __shfl_xor(x1, 32);
+    const float rk = h == hk ? r0 : r0o, rk1 = h == hk ? r1 : r1o; // rows k, k1 of A, by column j
+    const float xk = h == hk ? x0 : x0o, xk1 = h == hk ? x1 : x1o; // rows k, k1 of X
+    const float akk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk), k));
+    const float ak1k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk1), k));
+    const float ak1k1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk1), k1));
+    fail |= (akk <= 0.f);
+    const float i11 = __builtin_amdgcn_rsqf(akk); // 1 / L(k,k)
+    const float l21 = ak1k * i11;
+    const float d2 = __builtin_fmaf(-l21, l21, ak1k1);
+    fail |= (d2 <= 0.f);
+    const float i22 = __builtin_amdgcn_rsqf(d2);
+    float lk = rk * i11;                             // L(j, k)
+    float lk1 = __builtin_fmaf(-l21, lk, rk1) * i22; // L(j, k1)
+    lk = j >= k ? lk : 0.f;
+    lk1 = j >= k1 ? lk1 : 0.f;
+    const float yk = xk * i11;                             // row k of L^-1
+    const float yk1 = __builtin_fmaf(-l21, yk, xk1) * i22; // row k1
+    if (h == hk) {
+      Xc[pk] = yk;
+      Xc[pk + 1] = yk1;
+    }
+    const float xa = h == 0 ? lk : lk1;
+    const float xm = j > k1 ? xa : 0.f; // rows <= k1 of X are final
+    const float yb = h == 0 ? yk : yk1;
+    Acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-xa, xa, Acc, 0, 0, 0);
+    Xc = __builtin_amdgcn_mfma_f32_32x32x2f32(-xm, yb, Xc, 0, 0, 0);
+  }
+  return fail;
+}
+
 template <int M>
 struct Layout {
   static constexpr int NODE = N * N + N;               // Q | delta
@@ -84,8 +135,16 @@ template <int M>
 __global__ __launch_bounds__(64) void chain_factor_solve_mf32(
     const float *__restrict__ mats, const float *__restrict__ vecs, float *__restrict__ sol,
     float *__restrict__ gains, float *__restrict__ wsp, int *__restrict__ status, const long batch,
-    const int T) {
+    const int T
+#ifdef SIP_LQR_STAMPS
+    , unsigned long long *__restrict__ stamps
+#endif
+) {
   static_assert(M >= 1 && M <= 8, "control rows must fit regs 0..3 of both halves");
+#ifdef SIP_LQR_STAMPS
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+  unsigned long long ts1 = 0;
+#endif
   using L = Layout<M>;
   constexpr int STG = L::NODE + L::EDGE, VSTG = L::VNODE + L::VEDGE;
   const long p = blockIdx.x;
@@ -99,7 +158,6 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mf32(
   float *pw = wsp + p * ((long)(T + 1) * L::WSN);
 
   __shared__ float s_v[N], s_t[N], s_g[N], s_sdi[N], s_h[8], s_k[8], s_x[N], s_z[N], s_u[8];
-  __shared__ float s_G[8 * 8];
 
   int stat = 0;
   f32x16 W, V;
@@ -128,53 +186,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mf32(
       Acc[q] = V[q] * s_x[crow(q, h)] * sd + (diag ? 1.f : 0.f);
       Xc[q] = diag ? 1.f : 0.f; // becomes X = L^-1
     }
-    // Cholesky (Eigen::LLT, lqr.cpp:505) and the triangular inverse together,
-    // two columns per step, as rank-2 eliminations on the matrix pipe: with
-    // [l_k l_k1] the two new columns of L (one entry per lane, by row),
-    //     A <- A - l_k l_k^T - l_k1 l_k1^T            (trailing update)
-    //     X <- X - l_k y_k^T - l_k1 y_k1^T, rows > k1   (forward substitution
-    //                                                  on the identity)
-    // where y_k, y_k1 are the finished rows k, k1 of X = L^-1.  Row k of the
-    // symmetric A (= its column k) sits across the lanes of half h_k in reg
-    // p_k.  Pivots are those of the unblocked Cholesky (a_kk - |L_k,0:k|^2), so
-    // "pivot <= 0" is detected as Eigen does.
-    bool fail = false;
-#pragma unroll
-    for (int pp = 0; pp < 16; ++pp) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int k = 2 * pp, k1 = k + 1;
-      const int hk = (k >> 2) & 1, pk = (k & 3) + 4 * (k >> 3);
-      const float r0 = Acc[pk], r1 = Acc[pk + 1], x0 = Xc[pk], x1 = Xc[pk + 1];
-      const float r0o = __shfl_xor(r0, 32), r1o = __shfl_xor(r1, 32);
-      const float x0o = __shfl_xor(x0, 32), x1o = __shfl_xor(x1, 32);
-      const float rk = h == hk ? r0 : r0o, rk1 = h == hk ? r1 : r1o; // rows k, k1 of A, by column j
-      const float xk = h == hk ? x0 : x0o, xk1 = h == hk ? x1 : x1o; // rows k, k1 of X
-      const float akk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk), k));
-      const float ak1k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk1), k));
-      const float ak1k1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rk1), k1));
-      fail |= (akk <= 0.f);
-      const float i11 = __builtin_amdgcn_rsqf(akk); // 1 / L(k,k)
-      const float l21 = ak1k * i11;
-      const float d2 = __builtin_fmaf(-l21, l21, ak1k1);
-      fail |= (d2 <= 0.f);
-      const float i22 = __builtin_amdgcn_rsqf(d2);
-      float lk = rk * i11;                                   // L(j, k)
-      float lk1 = __builtin_fmaf(-l21, lk, rk1) * i22;       // L(j, k1)
-      lk = j >= k ? lk : 0.f;
-      lk1 = j >= k1 ? lk1 : 0.f;
-      const float yk = xk * i11;                             // row k of L^-1
-      const float yk1 = __builtin_fmaf(-l21, yk, xk1) * i22; // row k1
-      if (h == hk) {
-        Xc[pk] = yk;
-        Xc[pk + 1] = yk1;
-      }
-      const float xa = h == 0 ? lk : lk1;
-      const float xm = j > k1 ? xa : 0.f; // rows <= k1 of X are final
-      const float yb = h == 0 ? yk : yk1;
-      Acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-xa, xa, Acc, 0, 0, 0);
-      Xc = __builtin_amdgcn_mfma_f32_32x32x2f32(-xm, yb, Xc, 0, 0, 0);
-    }
+    const bool fail = eliminate<16>(Acc, Xc, j, h);
     if (stat == 0 && fail)
       stat = 2; // F_FACTORIZATION_FAILURE
     // F^-1 = X^T X on the matrix pipe, then W = D^-1/2 (I - F^-1) D^-1/2
@@ -219,132 +231,126 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mf32(
         pw[(long)(i + 1) * L::WSN + N * N + j] = g;
       }
     }
-    f32x16 F, Z, G, H;
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-      F[q] = 0.f, Z[q] = 0.f;
-    prodT<32>(W, A, F); // F = W A
-    prodT<32>(W, B, Z); // Z = W B   (H_child^T)
-    // G = R + B^T Z ; H = M^T + B^T F   (rows < M: regs 0..3)
+    // Only rows < M (regs 0..3 of both halves) of the G and H tiles are
+    // nonzero: keep just those four registers of each, so that at most five
+    // full tiles are ever live (occupancy).
+    f32x16 F;
+    float G4[4], H4[4];
     const float *Mm = em + N * N + N * M, *Rm = Mm + N * M;
+    {
+      f32x16 Z, T1;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int r = q + 4 * h; // row of a (<= 8)-row tile for q < 4
-      G[q] = (q < 4 && r < M && j < M) ? Rm[j * M + r] : 0.f;
-      H[q] = (q < 4 && r < M) ? Mm[r * N + j] : 0.f; // M^T(r, j) = M(j, r)
+      for (int q = 0; q < 16; ++q) {
+        const int r = q + 4 * h; // row of a (<= 8)-row tile for q < 4
+        Z[q] = 0.f;
+        T1[q] = (q < 4 && r < M && j < M) ? Rm[j * M + r] : 0.f;
+      }
+      prodT<32>(W, B, Z);  // Z = W B   (H_child^T)
+      prodT<32>(B, Z, T1); // G = R + B^T Z
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        G4[q] = T1[q];
     }
-    prodT<32>(B, Z, G);
-    prodT<32>(B, F, H);
+    {
+      f32x16 T2;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int r = q + 4 * h;
+        F[q] = 0.f;
+        T2[q] = (q < 4 && r < M) ? Mm[r * N + j] : 0.f; // M^T(r, j) = M(j, r)
+      }
+      prodT<32>(W, A, F);  // F = W A
+      prodT<32>(B, F, T2); // H = M^T + B^T F
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        H4[q] = T2[q];
+    }
     __syncthreads();
     // h = r + B^T g  (lqr.cpp:783-784): value for control row j on lanes j < M
     {
       const float bg = matTvec(B, s_g, h);
       if (lane < M)
         s_h[lane] = nv[L::VNODE + lane] + bg;
-      // G to LDS (row r, col c at c * 8 + r)
+    }
+    // LLT of G (lqr.cpp:696-701) and G^-1 = X^T X on the m x m corner of a tile
+    float K4[4], Gi4[4];
+    {
+      f32x16 Ga, Gx, Gi;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        Ga[q] = q < 4 ? G4[q] : 0.f;
+        Gx[q] = (q < 4 && q + 4 * h == j) ? 1.f : 0.f;
+        Gi[q] = 0.f;
+      }
+      const bool gfail = eliminate<(M + 1) / 2>(Ga, Gx, j, h);
+      if (stat == 0 && gfail)
+        stat = 3; // G_FACTORIZATION_FAILURE
+      if constexpr (M % 2 == 1) { // the padded last column: pivot 0 -> row M of X is garbage
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          Gx[q] = (q + 4 * h < M && j < M) ? Gx[q] : 0.f;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (j < M && q + 4 * h < M)
-          s_G[j * 8 + q + 4 * h] = G[q];
+        Gi = __builtin_amdgcn_mfma_f32_32x32x2f32(Gx[q], Gx[q], Gi, 0, 0, 0); // G^-1 = X^T X
+      // [K | k] = -G^-1 [H | h]   (lqr.cpp:707-713, 785-791); G^-1 symmetric
+      f32x16 Kt;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        Kt[q] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Gi4[q] = Gi[q];
+        Kt = __builtin_amdgcn_mfma_f32_32x32x2f32(Gi[q], H4[q], Kt, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        K4[q] = -Kt[q]; // K(q + 4h, j)
     }
     __syncthreads();
-    // Cholesky of G (m x m) redundantly in every lane; K = -G^-1 H per column
-    float Lg[8][8], ri[8];
-    bool gfail = false;
+    float kvj; // k_j on lanes j < M
+    {
+      float s2 = 0.f;
 #pragma unroll
-    for (int c2 = 0; c2 < M; ++c2)
-#pragma unroll
-      for (int r = c2; r < M; ++r)
-        Lg[r][c2] = s_G[c2 * 8 + r]; // lower triangle (Eigen reads only it)
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-      float d = Lg[k][k];
-#pragma unroll
-      for (int c2 = 0; c2 < k; ++c2)
-        d = __builtin_fmaf(-Lg[k][c2], Lg[k][c2], d);
-      gfail |= (d <= 0.f);
-      const float r1 = 1.f / sqrtf(d);
-      ri[k] = r1;
-#pragma unroll
-      for (int r = k + 1; r < M; ++r) {
-        float s = Lg[r][k];
-#pragma unroll
-        for (int c2 = 0; c2 < k; ++c2)
-          s = __builtin_fmaf(-Lg[r][c2], Lg[k][c2], s);
-        Lg[r][k] = s * r1;
-      }
+      for (int q = 0; q < 4; ++q)
+        s2 = __builtin_fmaf(Gi4[q], (q + 4 * h < M) ? s_h[q + 4 * h] : 0.f, s2);
+      kvj = -(s2 + __shfl_xor(s2, 32));
     }
-    if (stat == 0 && gfail)
-      stat = 3; // G_FACTORIZATION_FAILURE
-    auto g_solve = [&](float(&y)[8]) { // y <- -(L L^T)^-1 y
-#pragma unroll
-      for (int r = 0; r < M; ++r) {
-        float s = y[r];
-#pragma unroll
-        for (int c2 = 0; c2 < r; ++c2)
-          s = __builtin_fmaf(-Lg[r][c2], y[c2], s);
-        y[r] = s * ri[r];
-      }
-#pragma unroll
-      for (int r = M - 1; r >= 0; --r) {
-        float s = y[r];
-#pragma unroll
-        for (int c2 = r + 1; c2 < M; ++c2)
-          s = __builtin_fmaf(-Lg[c2][r], y[c2], s);
-        y[r] = s * ri[r];
-      }
-#pragma unroll
-      for (int r = 0; r < M; ++r)
-        y[r] = -y[r];
-    };
-    float Kc[8], kv[8], Hc8[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { // column j of H: rows q (h = 0) and q + 4 (h = 1)
-      const float own = H[q], other = __shfl_xor(own, 32);
-      Hc8[q] = h == 0 ? own : other;
-      Hc8[q + 4] = h == 0 ? other : own;
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      Kc[r] = r < M ? Hc8[r] : 0.f;
-      kv[r] = r < M ? s_h[r] : 0.f;
-    }
-    g_solve(Kc); // [K | k] = -G^-1 [H | h]   (lqr.cpp:707-713, 785-791)
-    g_solve(kv);
     // gains out: K (m x 32 col-major) | k
-    if (h == 0) {
-      float *gi = pg + (long)i * L::GAIN + j * M;
+    {
+      float *gi = pg + (long)i * L::GAIN;
 #pragma unroll
-      for (int r = 0; r < M; ++r)
-        gi[r] = Kc[r];
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int r = 0; r < M; ++r)
-        pg[(long)i * L::GAIN + M * N + r] = kv[r];
+      for (int q = 0; q < 4; ++q)
+        if (q + 4 * h < M)
+          gi[j * M + q + 4 * h] = K4[q];
+      if (lane < M)
+        gi[M * N + lane] = kvj;
     }
     // v = q + A^T g + K^T h   (lqr.cpp:793-794)
     {
-      float vn = nv[j] + matTvec(A, s_g, h);
+      float kh = 0.f;
 #pragma unroll
-      for (int r = 0; r < M; ++r)
-        vn = __builtin_fmaf(Kc[r], s_h[r], vn);
+      for (int q = 0; q < 4; ++q)
+        kh = __builtin_fmaf(K4[q], (q + 4 * h < M) ? s_h[q + 4 * h] : 0.f, kh);
+      kh += __shfl_xor(kh, 32);
+      const float vn = nv[j] + matTvec(A, s_g, h) + kh;
       __syncthreads(); // everyone is done with s_v / s_t / s_g of the child
       if (h == 0)
         s_v[j] = vn;
     }
     // V = Q + A^T F + K^T H   (lqr.cpp:715-719)
-    f32x16 Kt;
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-      Kt[q] = q < 4 ? (h == 0 ? Kc[q] : Kc[q + 4]) : 0.f;
     V = load_c32(nm, N, j, h);
     prodT<32>(A, F, V);
-    prodT<8>(Kt, H, V);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) // K^T H: the row pairs (q, q + 4) are the K = 2 slices
+      V = __builtin_amdgcn_mfma_f32_32x32x2f32(K4[q], H4[q], V, 0, 0, 0);
     __syncthreads();
     finish_node(i);
   }
 
+#ifdef SIP_LQR_STAMPS
+  ts1 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- root: g_0 = v_0 + W_0 t_0 ; x_0 = c_0 - delta_0 o g_0, y_0 = g_0 -------
   {
     const float wt = matTvec(W, s_t, h);
@@ -413,6 +419,12 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mf32(
     }
     __syncthreads();
   }
+#ifdef SIP_LQR_STAMPS
+  if (stamps != nullptr && lane == 0) {
+    unsigned long long *o = stamps + (long)blockIdx.x * 24;
+    o[0] = ts0, o[1] = ts0, o[2] = ts1, o[3] = ts1, o[4] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
 
 } // namespace mf32

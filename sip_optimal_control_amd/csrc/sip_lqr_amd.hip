@@ -74,7 +74,7 @@ hipError_t launch_mf32(const sip_lqr_plan *pl, const void *mats, const void *vec
                        int32_t *status, void *ws, hipStream_t stream) {
   hipLaunchKernelGGL((sipamd::mf32::chain_factor_solve_mf32<M>), dim3((unsigned)pl->batch), dim3(64), 0,
                      stream, (const float *)mats, (const float *)vecs, (float *)sol, (float *)gains,
-                     (float *)ws, (int *)status, (long)pl->batch, pl->T);
+                     (float *)ws, (int *)status, (long)pl->batch, pl->T SIP_STAMP_PASS);
   return hipGetLastError();
 }
 

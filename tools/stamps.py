@@ -9,12 +9,14 @@ from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
 from sip_optimal_control_amd._lib import load_library
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-n, m, T = 12, 4, 50
+c4 = len(sys.argv) > 2 and sys.argv[2] == "c4"
+n, m, T = (32, 8, 100) if c4 else (12, 4, 50)
+dtype = torch.float32 if c4 else torch.float64
 shape = ChainShape(n, m, T)
-mats, vecs = synthetic.make_chain_batch(shape, batch, seed=1, device="cuda:0")
-solver = BatchedChainLQR(n, m, T, batch, device="cuda:0")
+mats, vecs = synthetic.make_chain_batch(shape, batch, seed=1, device="cuda:0", dtype=dtype)
+solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device="cuda:0")
 lib = load_library()
-waves = (batch + 3) // 4
+waves = batch if c4 else (batch + 3) // 4
 st = torch.zeros(waves * 24, dtype=torch.int64, device="cuda:0")
 fn = ctypes.CDLL(os.environ["SIP_LQR_LIB"]).sip_lqr_debug_set_stamps
 fn.argtypes = [ctypes.c_void_p]
