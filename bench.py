@@ -215,6 +215,16 @@ def main():
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes * batch,
             },
         }
+        if dt == "f32":
+            # C4 sits above the fp32 ridge -> matrix-core roofline
+            # (dense f32 MFMA peak 157.3 TFLOP/s, MI355X_MICROARCH.md); HBM fraction kept alongside
+            tflops = shape.algorithmic_flops() * batch / (kernel_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s",
+                "frac": tflops / 157.3, "traffic": traffic, "kernel_ms": kernel_ms,
+                "algorithmic_flops_per_launch": shape.algorithmic_flops() * batch,
+                "hbm_achieved_gbs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, mats, vecs, args.cpu_seconds)
         print(json.dumps(out), flush=True)

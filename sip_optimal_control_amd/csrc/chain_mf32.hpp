@@ -367,57 +367,80 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mf32(
   __syncthreads();
 
   // ---- forward rollout (lqr.cpp:821-870) -------------------------------------
-  for (int i = 0; i < T; ++i) {
+  // Everything stage i + 1 reads from memory is requested while stage i runs
+  // (registers): none of it depends on x.
+  struct FwdStage {
+    float KT[16], AT[16], Bj[8]; // K(j, r(q,h)), A(j, r(q,h)), B(j, 0..M-1) of this lane's row j
+    f32x16 Wc;                   // W of the child (C/D-layout dump)
+    float kj, gj, cj, dj;        // k_j, g_c(j), c_c(j), delta_c(j)
+  };
+  auto fetch_stage = [&](const int i, FwdStage &f) {
     const float *em = pm + (long)i * STG + L::NODE;
     const float *nm1 = pm + (long)(i + 1) * STG;
     const float *nv1 = pv + (long)(i + 1) * VSTG;
     const float *gi = pg + (long)i * L::GAIN;
     const float *wn = pw + (long)(i + 1) * L::WSN;
-    // u = k + K x : lane j < M owns control row j; K(j, r) at r * M + j
-    {
-      float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        s = __builtin_fmaf(j < M ? gi[crow(q, h) * M + j] : 0.f, s_x[crow(q, h)], s);
-      s += __shfl_xor(s, 32);
-      if (lane < M)
-        s_u[lane] = gi[M * N + lane] + s;
+    for (int q = 0; q < 16; ++q) {
+      f.KT[q] = j < M ? gi[crow(q, h) * M + j] : 0.f; // K(j, r) at r * M + j
+      f.AT[q] = em[crow(q, h) * N + j];               // A(j, r) at r * 32 + j
     }
-    __syncthreads();
-    // z = A x + B u : lane j owns state row j; A(j, r) at r * 32 + j
-    float z = 0.f;
-    {
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        z = __builtin_fmaf(em[crow(q, h) * N + j], s_x[crow(q, h)], z);
-      z += __shfl_xor(z, 32);
-#pragma unroll
-      for (int r = 0; r < M; ++r)
-        z = __builtin_fmaf(em[N * N + r * N + j], s_u[r], z);
-    }
-    if (h == 0)
-      s_z[j] = z;
-    __syncthreads();
-    // y_c = g_c + W_c z ; x_c = z + c_c - delta_c o y_c
-    f32x16 Wc;
+    for (int r = 0; r < M; ++r)
+      f.Bj[r] = em[N * N + r * N + j];
     const f32x4 *wd = (const f32x4 *)wn;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 v4 = wd[g * 64 + lane];
-      Wc[4 * g] = v4[0], Wc[4 * g + 1] = v4[1], Wc[4 * g + 2] = v4[2], Wc[4 * g + 3] = v4[3];
+      f.Wc[4 * g] = v4[0], f.Wc[4 * g + 1] = v4[1], f.Wc[4 * g + 2] = v4[2], f.Wc[4 * g + 3] = v4[3];
     }
-    const float y = wn[N * N + j] + matTvec(Wc, s_z, h);
-    const float xn = z + (nv1[N + j] - nm1[N * N + j] * y);
+    f.kj = lane < M ? gi[M * N + lane] : 0.f;
+    f.gj = wn[N * N + j];
+    f.cj = nv1[N + j];
+    f.dj = nm1[N * N + j];
+  };
+  FwdStage cur, nxt;
+  if (T > 0)
+    fetch_stage(0, cur);
+  for (int i = 0; i < T; ++i) {
+    if (i + 1 < T)
+      fetch_stage(i + 1, nxt);
+    // u = k + K x : lane j < M owns control row j
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        s = __builtin_fmaf(cur.KT[q], s_x[crow(q, h)], s);
+      s += __shfl_xor(s, 32);
+      if (lane < M)
+        s_u[lane] = cur.kj + s;
+    }
+    __syncthreads();
+    // z = A x + B u : lane j owns state row j
+    float z = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      z = __builtin_fmaf(cur.AT[q], s_x[crow(q, h)], z);
+    z += __shfl_xor(z, 32);
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+      z = __builtin_fmaf(cur.Bj[r], s_u[r], z);
+    if (h == 0)
+      s_z[j] = z;
+    __syncthreads();
+    // y_c = g_c + W_c z ; x_c = z + c_c - delta_c o y_c
+    const float y = cur.gj + matTvec(cur.Wc, s_z, h);
+    const float xn = z + (cur.cj - cur.dj * y);
     float *si = ps + (long)i * VSTG;
     if (lane < M)
       si[2 * N + lane] = s_u[lane];
-    __syncthreads();
     if (h == 0) {
       si[VSTG + j] = xn;
       si[VSTG + N + j] = y;
       s_x[j] = xn;
     }
     __syncthreads();
+    cur = nxt;
   }
 #ifdef SIP_LQR_STAMPS
   if (stamps != nullptr && lane == 0) {
