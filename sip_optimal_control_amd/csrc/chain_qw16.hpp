@@ -166,6 +166,16 @@ __device__ __forceinline__ bool node_factor(const double (&V)[N], const double d
   return fail;
 }
 
+// Cache policy of the LDS-DMA streams of the problem inputs (each byte is read
+// once per sweep direction): 2 = nt, 0 = default.  nt keeps the once-read
+// inputs from evicting what the rollout re-reads (gains, [W | g] spill):
+// measured +3.5 % at C3 (A/B in one process, tools/ab.sh).
+#ifndef SIP_LQR_NT_SOL
+#define SIP_LQR_NT_SOL 0
+#endif
+#ifndef SIP_LQR_NT_IN
+#define SIP_LQR_NT_IN 2
+#endif
 typedef __attribute__((address_space(3))) char lds_char;
 typedef const __attribute__((address_space(3))) double lds_cdouble;
 
@@ -220,6 +230,8 @@ struct StageDma {
     });
   }
   // base: wave-uniform pointer to the region of the wave's first problem.
+  // AUX: cache-policy bits of the load (0 default, 2 = nt for once-read bytes).
+  template <int AUX = 0>
   __device__ __forceinline__ void issue(const char *base, lds_char *dst,
                                         const int lane) const {
     sfor<0, INSTR>([&](auto jj) {
@@ -228,13 +240,13 @@ struct StageDma {
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void *)(base + off[j]),
             (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0,
-            0);
+            AUX);
       } else {
         if (j * 64 + lane < 4 * PIECES)
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void *)(base + off[j]),
               (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
-              0, 0);
+              0, AUX);
       }
     });
   }
@@ -530,9 +542,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     dma_bv.init(lane, (unsigned)(vecs_len * 8), max_rel);
     if (T > 0) {
       lds_char *buf = lds + ((T - 1) & 1) * C::B_BYTES;
-      dma_bm.issue((const char *)(mats + p0 * mats_len + (long)(T - 1) * STG),
+      dma_bm.template issue<SIP_LQR_NT_IN>((const char *)(mats + p0 * mats_len + (long)(T - 1) * STG),
                    buf, lane);
-      dma_bv.issue((const char *)(vecs + p0 * vecs_len + (long)(T - 1) * VSTG),
+      dma_bv.template issue<SIP_LQR_NT_IN>((const char *)(vecs + p0 * vecs_len + (long)(T - 1) * VSTG),
                    buf + C::BM::BYTES, lane);
     }
   }
@@ -565,9 +577,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       SIP_SEG(0);
       if (i > 0) { // next stage streams into the other buffer meanwhile
         lds_char *nbuf = lds + ((i - 1) & 1) * C::B_BYTES;
-        dma_bm.issue((const char *)(mats + p0 * mats_len + (long)(i - 1) * STG),
+        dma_bm.template issue<SIP_LQR_NT_IN>((const char *)(mats + p0 * mats_len + (long)(i - 1) * STG),
                      nbuf, lane);
-        dma_bv.issue(
+        dma_bv.template issue<SIP_LQR_NT_IN>(
             (const char *)(vecs + p0 * vecs_len + (long)(i - 1) * VSTG),
             nbuf + C::BM::BYTES, lane);
         asm volatile("" ::: "memory"); // stores of this stage stay younger
@@ -643,15 +655,15 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     dma_fd.init(lane, (unsigned)(mats_len * 8), max_rel);
   }
   auto issue_forward = [&](const int i, lds_char *buf) {
-    dma_fa.issue((const char *)(mats + p0 * mats_len + (long)i * STG + L::NODE),
+    dma_fa.template issue<SIP_LQR_NT_IN>((const char *)(mats + p0 * mats_len + (long)i * STG + L::NODE),
                  buf, lane);
     dma_fg.issue((const char *)(gains + p0 * gains_len + (long)i * L::GAIN),
                  buf + C::FA::BYTES, lane);
     dma_fw.issue((const char *)(wsp + p0 * ws_len + (long)(i + 1) * WSN),
                  buf + C::FA::BYTES + C::FG::BYTES, lane);
-    dma_fc.issue((const char *)(vecs + p0 * vecs_len + (long)(i + 1) * VSTG + N),
+    dma_fc.template issue<SIP_LQR_NT_IN>((const char *)(vecs + p0 * vecs_len + (long)(i + 1) * VSTG + N),
                  buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES, lane);
-    dma_fd.issue(
+    dma_fd.template issue<SIP_LQR_NT_IN>(
         (const char *)(mats + p0 * mats_len + (long)(i + 1) * STG + N * N),
         buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES + C::FC::BYTES, lane);
   };
@@ -740,12 +752,21 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     x = z + (cc - dd * y);
     if (valid) {
       double *si = ps + (long)i * VSTG;
+#if SIP_LQR_NT_SOL
+      if (c < M)
+        __builtin_nontemporal_store(u, si + 2 * N + c);
+      if (isM) {
+        __builtin_nontemporal_store(x, si + VSTG + c);
+        __builtin_nontemporal_store(y, si + VSTG + N + c);
+      }
+#else
       if (c < M)
         si[2 * N + c] = u;
       if (isM) {
         si[VSTG + c] = x;
         si[VSTG + N + c] = y;
       }
+#endif
     }
     if constexpr (STAGED) {
       // Keep the stores above older than the DMA below (see the vmcnt count).
