@@ -470,13 +470,19 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       });
     }
     if constexpr (STAGED) {
-      auto a_src = isV ? (lds_cdouble *)my_t : em + cm * N;
-      auto f_src = isV ? (lds_cdouble *)my_v : zeros;
-      sfor<0, N>([&](auto kk) {
+      // 16-byte aligned columns (N even): let the compiler use ds_read_b128
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      typedef const __attribute__((address_space(3))) d2 lds_cd2;
+      lds_cd2 *a_src = (lds_cd2 *)(isV ? (lds_cdouble *)my_t : em + cm * N);
+      lds_cd2 *f_src = (lds_cd2 *)(isV ? (lds_cdouble *)my_v : zeros);
+      lds_cd2 *b_src = (lds_cd2 *)(em + N * N + cu * N);
+      static_assert(N % 2 == 0, "staged kernel: even N");
+      sfor<0, N / 2>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
-        Aaug[k] = a_src[k]; // vector lane: t
-        F[k] = f_src[k];    // vector lane accumulates g = v_c + W t
-        Bcol[k] = em[N * N + cu * N + k];
+        const d2 a2 = a_src[k], f2 = f_src[k], b2 = b_src[k];
+        Aaug[2 * k] = a2[0], Aaug[2 * k + 1] = a2[1]; // vector lane: t
+        F[2 * k] = f2[0], F[2 * k + 1] = f2[1];       // vector lane accumulates g = v_c + W t
+        Bcol[2 * k] = b2[0], Bcol[2 * k + 1] = b2[1];
       });
     } else {
       sfor<0, N>([&](auto kk) {
