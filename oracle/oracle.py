@@ -38,8 +38,9 @@ class _Workspace(ctypes.Structure):
 
 
 def build(force=False):
+    sources = [os.path.join(_HERE, f) for f in ("lqr_oracle.c", "lqr_oracle.h", "kkt_oracle.c", "kkt_oracle.h")]
     if force or not os.path.exists(_SO) or \
-            os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "lqr_oracle.c")):
+            os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in sources):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
