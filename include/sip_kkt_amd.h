@@ -1,0 +1,164 @@
+/*
+ * sip_kkt_amd.h -- C ABI of the batched Newton-KKT step on MI355X (gfx950):
+ * the caller either side of the Riccati path (SURVEY.md section 8, rows f1
+ * and f4), device-resident, for `batch` problems that share one topology and
+ * dimension table (theta_dim == 0).
+ *
+ * Replaces, of /root/reference/sip_optimal_control (class CallbackProvider,
+ * helpers.hpp:7-33):
+ *   factor(w, r1, r2, r3)   helpers.cpp:242-370   -> sip_kkt_factor
+ *   solve(b, sol)           helpers.cpp:749-893   -> sip_kkt_solve
+ *   factor + solve          newton_kkt_benchmark.cpp:316-324 (loop body of
+ *                           BM_NewtonKKTFactorSolve)  -> sip_kkt_factor_solve
+ *   add_Kx_to_y(...)        helpers.cpp:953-1368  -> sip_kkt_add_Kx_to_y
+ * The Riccati solve in the middle is the library's own LQR path
+ * (sip_lqr_amd.h): uniform chains use the packed chain layout and its fused
+ * kernels, everything else the general tree engine.
+ *
+ * Not covered: global variables theta (theta_dim > 0: the multi-RHS solve and
+ * Schur complement, helpers.cpp:372-747, 896-951).
+ *
+ * Data (all double, device memory, problem p at p * per-problem length):
+ *
+ *  model  [sip_kkt_len(plan, SIP_KKT_LEN_MODEL)] per problem -- the fields of
+ *    NodeModelCallbackOutput / EdgeModelCallbackOutput (types.hpp:48-89)
+ *    that the path reads, column-major compact blocks, node i followed by
+ *    edge i:
+ *      node i : d2L_dx2 (n_i x n_i) | dc_dx (c_i x n_i) | dg_dx (g_i x n_i)
+ *      edge e : d2L_dx2 (np x np) | d2L_dxdu (np x m) | d2L_du2 (m x m) |
+ *               ddyn_dx (nc x np) | ddyn_du (nc x m) | dc_dx (ce x np) |
+ *               dc_du (ce x m) | dg_dx (ge x np) | dg_du (ge x m)
+ *    (np / nc: state dimension of the edge's parent / child), block offsets
+ *    from sip_kkt_model_offset().
+ *  KKT vectors: the reference's flattened ordering (types.cpp:24-64,
+ *    offsets from sip_kkt_vector_offset()):
+ *      x [x_dim]: per node i: state_i, then (i < num_edges) control_i
+ *      y [y_dim]: per node i: dyn_i (n_i) | node_c_i; then per edge edge_c_e
+ *      z [z_dim]: per node i: node_g_i; then per edge edge_g_e
+ *    r1 [x_dim], r2 [y_dim], w and r3 [z_dim]; b and sol [x_dim+y_dim+z_dim]
+ *    = [x | y | z].
+ *
+ * Error conventions: functions return SIP_LQR_OK or a SIP_LQR_ERR_* code of
+ * sip_lqr_amd.h for API misuse / HIP failures.  Numerical outcomes are
+ * per-problem int32 status words: 0 where the reference's factor() returns
+ * true; otherwise the reason it returned false (values below).  sol of a
+ * problem whose status != 0 is left untouched.  No host fallback.
+ */
+#ifndef SIP_KKT_AMD_H
+#define SIP_KKT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sip_lqr_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status[p]: 0..4 = LQR::FactorStatus (lqr.hpp:68-74) from the Riccati
+ * factorization; the rest are the other `return false` exits of
+ * CallbackProvider::factor. */
+enum {
+  SIP_KKT_SUCCESS = 0,
+  SIP_KKT_NONPOSITIVE_REGULARIZATION = 5, /* r2 <= 0 or w + r3 <= 0, helpers.cpp:256-297 */
+  SIP_KKT_INVALID_INPUT = 6               /* validate_input() failed, helpers.cpp:244-246 */
+};
+
+/* per-problem lengths in doubles for sip_kkt_len() */
+enum {
+  SIP_KKT_LEN_X = 0,  /* Dimensions::get_x_dim, lqr.cpp:153-155 */
+  SIP_KKT_LEN_Y = 1,  /* Dimensions::get_y_dim, lqr.cpp:157-165 */
+  SIP_KKT_LEN_Z = 2,  /* Dimensions::get_z_dim, lqr.cpp:167-175 */
+  SIP_KKT_LEN_MODEL = 3
+};
+
+/* blocks of the model arena for sip_kkt_model_offset() */
+enum {
+  SIP_KKT_NODE_D2L_DX2 = 0, SIP_KKT_NODE_DC_DX, SIP_KKT_NODE_DG_DX,
+  SIP_KKT_EDGE_D2L_DX2, SIP_KKT_EDGE_D2L_DXDU, SIP_KKT_EDGE_D2L_DU2,
+  SIP_KKT_EDGE_DDYN_DX, SIP_KKT_EDGE_DDYN_DU, SIP_KKT_EDGE_DC_DX,
+  SIP_KKT_EDGE_DC_DU, SIP_KKT_EDGE_DG_DX, SIP_KKT_EDGE_DG_DU,
+  SIP_KKT_NUM_BLOCKS
+};
+
+/* offset tables of the flattened KKT vectors (Workspace::x_state_offsets
+ * ... z_edge_offsets, types.cpp:33-63) for sip_kkt_vector_offset() */
+enum {
+  SIP_KKT_X_STATE = 0, SIP_KKT_X_CONTROL, SIP_KKT_Y_DYN, SIP_KKT_Y_NODE_C,
+  SIP_KKT_Y_EDGE_C, SIP_KKT_Z_NODE, SIP_KKT_Z_EDGE
+};
+
+typedef struct sip_kkt_plan sip_kkt_plan;
+
+/* Replaces: CallbackProvider::CallbackProvider (helpers.cpp:11-26) +
+ * validate_input (types.cpp:68-127) + populate_workspace_metadata
+ * (types.cpp:24-64).  Any of the four constraint-dimension arrays may be NULL
+ * (all zero), as Dimensions::get_node_c_dim & co allow (lqr.cpp:98-112).  An
+ * invalid input is latched: the plan is created and every factor call reports
+ * SIP_KKT_INVALID_INPUT (or the traversal's INVALID_TOPOLOGY) for all
+ * problems, like input_is_valid_ (helpers.cpp:24-26, 244-246). */
+int sip_kkt_plan_create(int64_t batch, int num_edges, int root,
+                        const int *edge_parents, const int *edge_children,
+                        const int *state_dims, const int *control_dims,
+                        const int *node_c_dims, const int *node_g_dims,
+                        const int *edge_c_dims, const int *edge_g_dims,
+                        int device, sip_kkt_plan **plan);
+void sip_kkt_plan_destroy(sip_kkt_plan *plan);
+
+/* 0 if the input validated, else the status every factor call will report. */
+int sip_kkt_input_status(const sip_kkt_plan *plan);
+size_t sip_kkt_len(const sip_kkt_plan *plan, int which);
+/* (size_t)-1 for an out-of-range request */
+size_t sip_kkt_model_offset(const sip_kkt_plan *plan, int block, int index);
+size_t sip_kkt_vector_offset(const sip_kkt_plan *plan, int table, int index);
+/* Bytes of device scratch for the whole batch: the condensed LQR problem
+ * (Workspace::RegularizedLQRData, types.hpp:163-176: Q_mod, M_mod, R_mod,
+ * q_mod, r_mod, c_mod, dyn_r2, the 1/r2 and 1/(w+r3) weights), the LQR
+ * output and the Riccati factor state (LQR::Workspace, lqr.hpp:109-135). */
+size_t sip_kkt_work_bytes(const sip_kkt_plan *plan);
+/* which Riccati path the plan runs, e.g. "chain:chain_factor_solve_qw16<...>"
+ * or "tree:general" */
+const char *sip_kkt_kernel_name(const sip_kkt_plan *plan);
+
+/* Replaces CallbackProvider::factor (helpers.cpp:242-370): checks and inverts
+ * the regularization, condenses the constraint Jacobians into Q_mod / M_mod /
+ * R_mod (rank-c / rank-g symmetric updates, helpers.cpp:79-136, 299-361) and
+ * runs the Riccati factorization.  Writes status[p].  Asynchronous on
+ * `stream`. */
+int sip_kkt_factor(const sip_kkt_plan *plan, const double *d_model,
+                   const double *d_w, const double *d_r1, const double *d_r2,
+                   const double *d_r3, void *d_work, int32_t *d_status,
+                   void *stream);
+
+/* Replaces CallbackProvider::solve (helpers.cpp:896-900 -> 749-893) against
+ * the last sip_kkt_factor() on the same d_work: builds q_mod / r_mod / c_mod
+ * from b, runs LQR::solve, recovers the constraint multipliers y_c, z.  May
+ * be called repeatedly with new right-hand sides.  d_status: as written by
+ * sip_kkt_factor (problems with status != 0 are skipped). */
+int sip_kkt_solve(const sip_kkt_plan *plan, const double *d_model,
+                  const double *d_b, double *d_sol, void *d_work,
+                  const int32_t *d_status, void *stream);
+
+/* factor() followed by solve() (the loop body of BM_NewtonKKTFactorSolve,
+ * benchmarks/newton_kkt_benchmark.cpp:316-324), with the Riccati part as the
+ * fused launch of sip_lqr_factor_solve() when the plan is a uniform chain. */
+int sip_kkt_factor_solve(const sip_kkt_plan *plan, const double *d_model,
+                         const double *d_w, const double *d_r1,
+                         const double *d_r2, const double *d_r3,
+                         const double *d_b, double *d_sol, void *d_work,
+                         int32_t *d_status, void *stream);
+
+/* Replaces CallbackProvider::add_Kx_to_y (helpers.cpp:953-976, with
+ * add_Hx/Cx/CTx/Gx/GTx_to_y, :978-1368): y += K x for
+ *   K = [[H + r1, C^T, G^T], [C, -r2, 0], [G, 0, -(w + r3)]],
+ * x and y being [x | y | z] vectors of every problem. */
+int sip_kkt_add_Kx_to_y(const sip_kkt_plan *plan, const double *d_model,
+                        const double *d_w, const double *d_r1,
+                        const double *d_r2, const double *d_r3,
+                        const double *d_x, double *d_y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

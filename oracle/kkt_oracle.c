@@ -517,8 +517,8 @@ static void gemv_t(double *y, const double *J, int rows, int cols, const double 
 }
 
 /* CallbackProvider::add_Kx_to_y, helpers.cpp:953-976, with add_Hx_to_y
- * (:978-1020), add_Cx_to_y (:1068-1122), add_CTx_to_y (:1150-1212),
- * add_Gx_to_y (:1243-1277), add_GTx_to_y (:1305-1339); theta_dim == 0. */
+ * (:979-1022), add_Cx_to_y (:1070-1126), add_CTx_to_y (:1161-1219),
+ * add_Gx_to_y (:1252-1283), add_GTx_to_y (:1311-1342); theta_dim == 0. */
 void kkt_oracle_add_Kx_to_y(const kkt_oracle *o, const double *model, const double *w,
                             const double *r1, const double *r2, const double *r3,
                             const double *xv, double *yv) {

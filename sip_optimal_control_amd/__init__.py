@@ -10,10 +10,12 @@ every solve requires the HIP library and a device.
 from ._lib import LQRLibraryError, load_library, library_path  # noqa: F401
 from .layout import ChainShape  # noqa: F401
 from .chain import BatchedChainLQR, FactorStatus  # noqa: F401
+from .kkt import BatchedNewtonKKT  # noqa: F401
 from . import synthetic  # noqa: F401
 
 __all__ = [
     "BatchedChainLQR",
+    "BatchedNewtonKKT",
     "ChainShape",
     "FactorStatus",
     "LQRLibraryError",

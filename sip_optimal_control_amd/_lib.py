@@ -1,4 +1,5 @@
-"""ctypes binding of the C ABI declared in include/sip_lqr_amd.h.
+"""ctypes binding of the C ABI declared in include/sip_lqr_amd.h and
+include/sip_kkt_amd.h.
 
 Fails loudly (LQRLibraryError) when the HIP library is missing: the product
 has no fallback path.
@@ -55,6 +56,20 @@ _SIGNATURES = {
     "sip_lqr_tree_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "sip_lqr_kernel_name": (ctypes.c_char_p, [_P]),
     "sip_lqr_version": (ctypes.c_char_p, []),
+    # include/sip_kkt_amd.h
+    "sip_kkt_plan_create": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [_P] * 8 +
+                            [ctypes.c_int, _PP]),
+    "sip_kkt_plan_destroy": (None, [_P]),
+    "sip_kkt_input_status": (ctypes.c_int, [_P]),
+    "sip_kkt_len": (ctypes.c_size_t, [_P, ctypes.c_int]),
+    "sip_kkt_model_offset": (ctypes.c_size_t, [_P, ctypes.c_int, ctypes.c_int]),
+    "sip_kkt_vector_offset": (ctypes.c_size_t, [_P, ctypes.c_int, ctypes.c_int]),
+    "sip_kkt_work_bytes": (ctypes.c_size_t, [_P]),
+    "sip_kkt_kernel_name": (ctypes.c_char_p, [_P]),
+    "sip_kkt_factor": (ctypes.c_int, [_P] * 9),
+    "sip_kkt_solve": (ctypes.c_int, [_P] * 7),
+    "sip_kkt_factor_solve": (ctypes.c_int, [_P] * 11),
+    "sip_kkt_add_Kx_to_y": (ctypes.c_int, [_P] * 9),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,368 @@
+// kkt_kernels.hpp -- device side of the batched Newton-KKT step
+// (include/sip_kkt_amd.h): the work either side of the Riccati solve.
+//
+//   weights_kernel   1/r2, 1/(w+r3), positivity check   helpers.cpp:251-297
+//   condense_kernel  Q_mod, M_mod, R_mod, A, B, dyn_r2   helpers.cpp:299-367
+//   rhs_kernel       q_mod, r_mod, c_mod from b          helpers.cpp:752-812
+//   recover_kernel   x,u,y scatter + multipliers y_c, z  helpers.cpp:817-892
+//   apply_kernel     y += K x                            helpers.cpp:953-1368
+//
+// All of it is HBM-bound elementwise / rank-k work on small blocks: one
+// 64-lane workgroup per (problem, node-or-edge) item, lanes over the output
+// elements of the item, every output element accumulated by exactly one lane
+// in the reference's order (constraint-major, child edges in index order), so
+// there are no atomics and the result does not depend on scheduling.  A node
+// item gathers the contributions of its child edges (the reference scatters
+// them from the edge loop into the parent's block).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sipamd {
+namespace kkt {
+
+constexpr int TPB = 64;
+
+enum Block {
+  N_Q = 0, N_JC, N_JG, E_Q, E_M, E_R, E_A, E_B, E_JXC, E_JUC, E_JXG, E_JUG, NUM_BLOCKS
+};
+
+struct Meta {
+  int E, N, root;
+  int x_dim, y_dim, z_dim;
+  long model_len, in0_len, in1_len, out_len;
+  // dimension tables and traversal (per node / per edge)
+  const int *sd, *cd, *ncd, *ngd, *ecd, *egd, *parent, *child, *in_edge, *child_offsets, *child_edges;
+  // flattened KKT vector offsets, types.cpp:33-63
+  const int *x_state, *x_control, *y_dyn, *y_node_c, *y_edge_c, *z_node, *z_edge;
+  // 1 where a y row is a dynamics row (weight = r2 itself), else 0
+  const int *y_is_dyn;
+  const long *mo[NUM_BLOCKS]; // model arena block offsets
+  // offsets inside the LQR arenas (generic_plan.hpp tables)
+  const long *oQ, *od, *oq, *oc, *ox, *oy, *oA, *oB, *oM, *oR, *orr, *ou;
+};
+
+// inv[0 .. y_dim) : dyn rows r2, constraint rows 1/r2; inv[y_dim ..) : 1/(w+r3).
+// regstat[p] != 0 iff any regularization of problem p is <= 0.
+__global__ void __launch_bounds__(256)
+weights_kernel(const Meta mt, const double *__restrict__ w, const double *__restrict__ r2,
+               const double *__restrict__ r3, double *__restrict__ inv, int *__restrict__ regstat,
+               long batch) {
+  const long per = (long)mt.y_dim + mt.z_dim;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= batch * per)
+    return;
+  const long p = idx / per;
+  const int k = (int)(idx - p * per);
+  double reg, out;
+  if (k < mt.y_dim) {
+    reg = r2[p * mt.y_dim + k];
+    out = mt.y_is_dyn[k] ? reg : 1.0 / reg;
+  } else {
+    const long at = p * mt.z_dim + (k - mt.y_dim);
+    reg = w[at] + r3[at];
+    out = 1.0 / reg;
+  }
+  inv[idx] = out;
+  if (reg <= 0.0)
+    atomicOr(&regstat[p], 1);
+}
+
+__global__ void __launch_bounds__(256)
+merge_status_kernel(const int *__restrict__ regstat, int32_t *__restrict__ status, long batch, int code) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < batch && regstat[p] != 0)
+    status[p] = code;
+}
+
+// acc += sum_k (wgt[k] * Jb[k, cb]) * Ja[k, ca]   (J column-major, `rows` rows)
+__device__ __forceinline__ double rank_update(double acc, const double *Ja, int ca, const double *Jb, int cb,
+                                              int rows, const double *wgt) {
+  for (int k = 0; k < rows; ++k)
+    acc += (wgt[k] * Jb[k + (long)rows * cb]) * Ja[k + (long)rows * ca];
+  return acc;
+}
+
+__global__ void __launch_bounds__(TPB)
+condense_kernel(const Meta mt, const double *__restrict__ model_all, const double *__restrict__ r1_all,
+                const double *__restrict__ inv_all, double *__restrict__ in0_all, long batch) {
+  const int items = mt.N + mt.E;
+  const long p = blockIdx.x / items;
+  const int item = blockIdx.x - (unsigned)(p * items);
+  if (p >= batch)
+    return;
+  const double *model = model_all + p * mt.model_len;
+  const double *r1 = r1_all + p * mt.x_dim;
+  const double *yinv = inv_all + p * ((long)mt.y_dim + mt.z_dim), *zinv = yinv + mt.y_dim;
+  double *in0 = in0_all + p * mt.in0_len;
+  const int tid = threadIdx.x;
+  if (item < mt.N) {
+    const int i = item, n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];
+    const double *Q = model + mt.mo[N_Q][i], *Jc = model + mt.mo[N_JC][i], *Jg = model + mt.mo[N_JG][i];
+    double *Qm = in0 + mt.oQ[i], *dl = in0 + mt.od[i];
+    for (int d = tid; d < n; d += TPB)
+      dl[d] = yinv[mt.y_dyn[i] + d]; // dyn_r2, helpers.cpp:255-261
+    const int lo = mt.child_offsets[i], hi = mt.child_offsets[i + 1];
+    for (int idx = tid; idx < n * n; idx += TPB) {
+      const int col = idx / n, row = idx - col * n;
+      if (row < col)
+        continue;
+      double acc = Q[row + (long)n * col]; // lower triangle of d2L_dx2, :310-311
+      if (row == col)
+        acc += r1[mt.x_state[i] + row]; // :312-313
+      acc = rank_update(acc, Jc, row, Jc, col, c, yinv + mt.y_node_c[i]); // :314
+      acc = rank_update(acc, Jg, row, Jg, col, g, zinv + mt.z_node[i]);   // :315
+      for (int ci = lo; ci < hi; ++ci) { // the edge loop's additions to Q_mod[parent], :336-339
+        const int e = mt.child_edges[ci];
+        acc += (model + mt.mo[E_Q][e])[row + (long)n * col];
+        const double *Jxc = model + mt.mo[E_JXC][e], *Jxg = model + mt.mo[E_JXG][e];
+        acc = rank_update(acc, Jxc, row, Jxc, col, mt.ecd[e], yinv + mt.y_edge_c[e]);
+        acc = rank_update(acc, Jxg, row, Jxg, col, mt.egd[e], zinv + mt.z_edge[e]);
+      }
+      Qm[row + (long)n * col] = acc;
+      Qm[col + (long)n * row] = acc; // mirror_lower_to_upper, :357-361
+    }
+  } else {
+    const int e = item - mt.N, pa = mt.parent[e], n = mt.sd[pa], nc = mt.sd[mt.child[e]], m = mt.cd[e];
+    const int c = mt.ecd[e], g = mt.egd[e];
+    const double *Jxc = model + mt.mo[E_JXC][e], *Juc = model + mt.mo[E_JUC][e];
+    const double *Jxg = model + mt.mo[E_JXG][e], *Jug = model + mt.mo[E_JUG][e];
+    const double *wc = yinv + mt.y_edge_c[e], *wg = zinv + mt.z_edge[e];
+    const double *M = model + mt.mo[E_M][e], *R = model + mt.mo[E_R][e];
+    double *Mm = in0 + mt.oM[e], *Rm = in0 + mt.oR[e];
+    for (int idx = tid; idx < n * m; idx += TPB) { // M_mod, :341-343, 349-352
+      const int col = idx / n, row = idx - col * n;
+      double acc = M[idx];
+      acc = rank_update(acc, Jxc, row, Juc, col, c, wc);
+      acc = rank_update(acc, Jxg, row, Jug, col, g, wg);
+      Mm[idx] = acc;
+    }
+    for (int idx = tid; idx < m * m; idx += TPB) { // R_mod, :344-353
+      const int col = idx / m, row = idx - col * m;
+      if (row < col)
+        continue;
+      double acc = R[row + (long)m * col];
+      if (row == col)
+        acc += r1[mt.x_control[e] + row];
+      acc = rank_update(acc, Juc, row, Juc, col, c, wc);
+      acc = rank_update(acc, Jug, row, Jug, col, g, wg);
+      Rm[row + (long)m * col] = acc;
+      Rm[col + (long)m * row] = acc;
+    }
+    const double *A = model + mt.mo[E_A][e], *B = model + mt.mo[E_B][e]; // :365-366
+    double *Am = in0 + mt.oA[e], *Bm = in0 + mt.oB[e];
+    for (int idx = tid; idx < nc * n; idx += TPB)
+      Am[idx] = A[idx];
+    for (int idx = tid; idx < nc * m; idx += TPB)
+      Bm[idx] = B[idx];
+  }
+}
+
+// acc -= sum_k J[k, col] * (wgt[k] * rhs[k])   (subtract_weighted_jacobian_rhs, :138-153)
+__device__ __forceinline__ double sub_weighted(double acc, const double *J, int col, int rows,
+                                               const double *wgt, const double *rhs) {
+  for (int k = 0; k < rows; ++k)
+    acc -= J[k + (long)rows * col] * (wgt[k] * rhs[k]);
+  return acc;
+}
+
+__global__ void __launch_bounds__(TPB)
+rhs_kernel(const Meta mt, const double *__restrict__ model_all, const double *__restrict__ b_all,
+           const double *__restrict__ inv_all, double *__restrict__ in1_all, const int32_t *__restrict__ status,
+           long batch) {
+  const int items = mt.N + mt.E;
+  const long p = blockIdx.x / items;
+  const int item = blockIdx.x - (unsigned)(p * items);
+  if (p >= batch || (status != nullptr && status[p] != 0))
+    return;
+  const long kkt = (long)mt.x_dim + mt.y_dim + mt.z_dim;
+  const double *model = model_all + p * mt.model_len;
+  const double *b = b_all + p * kkt, *b_y = b + mt.x_dim, *b_z = b_y + mt.y_dim;
+  const double *yinv = inv_all + p * ((long)mt.y_dim + mt.z_dim), *zinv = yinv + mt.y_dim;
+  double *in1 = in1_all + p * mt.in1_len;
+  const int tid = threadIdx.x;
+  if (item < mt.N) {
+    const int i = item, n = mt.sd[i];
+    const int lo = mt.child_offsets[i], hi = mt.child_offsets[i + 1];
+    for (int d = tid; d < n; d += TPB) {
+      double acc = -b[mt.x_state[i] + d]; // :772
+      acc = sub_weighted(acc, model + mt.mo[N_JC][i], d, mt.ncd[i], yinv + mt.y_node_c[i], b_y + mt.y_node_c[i]);
+      acc = sub_weighted(acc, model + mt.mo[N_JG][i], d, mt.ngd[i], zinv + mt.z_node[i], b_z + mt.z_node[i]);
+      for (int ci = lo; ci < hi; ++ci) { // :805-806
+        const int e = mt.child_edges[ci];
+        acc = sub_weighted(acc, model + mt.mo[E_JXC][e], d, mt.ecd[e], yinv + mt.y_edge_c[e], b_y + mt.y_edge_c[e]);
+        acc = sub_weighted(acc, model + mt.mo[E_JXG][e], d, mt.egd[e], zinv + mt.z_edge[e], b_z + mt.z_edge[e]);
+      }
+      in1[mt.oq[i] + d] = acc;
+      in1[mt.oc[i] + d] = -b_y[mt.y_dyn[i] + d]; // c_mod, :776-777
+    }
+  } else {
+    const int e = item - mt.N, m = mt.cd[e];
+    for (int d = tid; d < m; d += TPB) {
+      double acc = -b[mt.x_control[e] + d]; // :807
+      acc = sub_weighted(acc, model + mt.mo[E_JUC][e], d, mt.ecd[e], yinv + mt.y_edge_c[e], b_y + mt.y_edge_c[e]);
+      acc = sub_weighted(acc, model + mt.mo[E_JUG][e], d, mt.egd[e], zinv + mt.z_edge[e], b_z + mt.z_edge[e]);
+      in1[mt.orr[e] + d] = acc;
+    }
+  }
+}
+
+// row k of J x  (J column-major rows x cols)
+__device__ __forceinline__ double row_dot(const double *J, int k, int rows, int cols, const double *x) {
+  double acc = 0.0;
+  for (int col = 0; col < cols; ++col)
+    acc += J[k + (long)rows * col] * x[col];
+  return acc;
+}
+
+__global__ void __launch_bounds__(TPB)
+recover_kernel(const Meta mt, const double *__restrict__ model_all, const double *__restrict__ b_all,
+               const double *__restrict__ inv_all, const double *__restrict__ out_all,
+               double *__restrict__ sol_all, const int32_t *__restrict__ status, long batch) {
+  const int items = mt.N + mt.E;
+  const long p = blockIdx.x / items;
+  const int item = blockIdx.x - (unsigned)(p * items);
+  if (p >= batch || status[p] != 0)
+    return;
+  const long kkt = (long)mt.x_dim + mt.y_dim + mt.z_dim;
+  const double *model = model_all + p * mt.model_len;
+  const double *b_y = b_all + p * kkt + mt.x_dim, *b_z = b_y + mt.y_dim;
+  const double *yinv = inv_all + p * ((long)mt.y_dim + mt.z_dim), *zinv = yinv + mt.y_dim;
+  const double *out = out_all + p * mt.out_len;
+  double *sol = sol_all + p * kkt, *sol_y = sol + mt.x_dim, *sol_z = sol_y + mt.y_dim;
+  const int tid = threadIdx.x;
+  if (item < mt.N) {
+    const int i = item, n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];
+    const double *x = out + mt.ox[i];
+    for (int d = tid; d < n; d += TPB) { // the aliasing of :817-824
+      sol[mt.x_state[i] + d] = x[d];
+      sol_y[mt.y_dyn[i] + d] = out[mt.oy[i] + d];
+    }
+    for (int k = tid; k < c + g; k += TPB) { // :828-855
+      if (k < c) {
+        const int at = mt.y_node_c[i] + k;
+        sol_y[at] = (row_dot(model + mt.mo[N_JC][i], k, c, n, x) - b_y[at]) * yinv[at];
+      } else {
+        const int at = mt.z_node[i] + (k - c);
+        sol_z[at] = (row_dot(model + mt.mo[N_JG][i], k - c, g, n, x) - b_z[at]) * zinv[at];
+      }
+    }
+  } else {
+    const int e = item - mt.N, pa = mt.parent[e], n = mt.sd[pa], m = mt.cd[e], c = mt.ecd[e], g = mt.egd[e];
+    const double *x = out + mt.ox[pa], *u = out + mt.ou[e];
+    for (int d = tid; d < m; d += TPB)
+      sol[mt.x_control[e] + d] = u[d];
+    for (int k = tid; k < c + g; k += TPB) { // :857-892
+      if (k < c) {
+        const int at = mt.y_edge_c[e] + k;
+        const double jx = row_dot(model + mt.mo[E_JXC][e], k, c, n, x);
+        const double ju = row_dot(model + mt.mo[E_JUC][e], k, c, m, u);
+        sol_y[at] = ((jx + ju) - b_y[at]) * yinv[at];
+      } else {
+        const int at = mt.z_edge[e] + (k - c);
+        const double jx = row_dot(model + mt.mo[E_JXG][e], k - c, g, n, x);
+        const double ju = row_dot(model + mt.mo[E_JUG][e], k - c, g, m, u);
+        sol_z[at] = ((jx + ju) - b_z[at]) * zinv[at];
+      }
+    }
+  }
+}
+
+// column `col` of J^T v : sum_k J[k, col] v[k]
+__device__ __forceinline__ double col_dot(const double *J, int col, int rows, const double *v) {
+  double acc = 0.0;
+  for (int k = 0; k < rows; ++k)
+    acc += J[k + (long)rows * col] * v[k];
+  return acc;
+}
+
+// y += K x, gather form: the lanes of a node item own the node's state rows of
+// y_x, its dynamics rows and node constraint rows of y_y, and its rows of y_z;
+// the lanes of an edge item own the control rows and the edge constraint rows.
+__global__ void __launch_bounds__(TPB)
+apply_kernel(const Meta mt, const double *__restrict__ model_all, const double *__restrict__ w_all,
+             const double *__restrict__ r1_all, const double *__restrict__ r2_all,
+             const double *__restrict__ r3_all, const double *__restrict__ x_all, double *__restrict__ y_all,
+             long batch) {
+  const int items = mt.N + mt.E;
+  const long p = blockIdx.x / items;
+  const int item = blockIdx.x - (unsigned)(p * items);
+  if (p >= batch)
+    return;
+  const long kkt = (long)mt.x_dim + mt.y_dim + mt.z_dim;
+  const double *model = model_all + p * mt.model_len;
+  const double *w = w_all + p * mt.z_dim, *r1 = r1_all + p * mt.x_dim, *r2 = r2_all + p * mt.y_dim;
+  const double *r3 = r3_all + p * mt.z_dim;
+  const double *x_x = x_all + p * kkt, *x_y = x_x + mt.x_dim, *x_z = x_y + mt.y_dim;
+  double *y_x = y_all + p * kkt, *y_y = y_x + mt.x_dim, *y_z = y_y + mt.y_dim;
+  const int tid = threadIdx.x;
+  if (item < mt.N) {
+    const int i = item, n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];
+    const double *xs = x_x + mt.x_state[i];
+    const int lo = mt.child_offsets[i], hi = mt.child_offsets[i + 1];
+    const int ine = mt.in_edge[i]; // -1 at the root
+    for (int r = tid; r < 2 * n + c + g; r += TPB) {
+      if (r < n) { // state rows of y_x: H x + C^T y + G^T z + r1 x
+        const int d = r;
+        double acc = row_dot(model + mt.mo[N_Q][i], d, n, n, xs);
+        acc += col_dot(model + mt.mo[N_JC][i], d, c, x_y + mt.y_node_c[i]);
+        acc += col_dot(model + mt.mo[N_JG][i], d, g, x_z + mt.z_node[i]);
+        acc -= x_y[mt.y_dyn[i] + d]; // -I of the node's own dynamics / initial-state row
+        for (int ci = lo; ci < hi; ++ci) {
+          const int e = mt.child_edges[ci], ch = mt.child[e], m = mt.cd[e];
+          acc += row_dot(model + mt.mo[E_Q][e], d, n, n, xs);
+          acc += row_dot(model + mt.mo[E_M][e], d, n, m, x_x + mt.x_control[e]);
+          acc += col_dot(model + mt.mo[E_A][e], d, mt.sd[ch], x_y + mt.y_dyn[ch]);
+          acc += col_dot(model + mt.mo[E_JXC][e], d, mt.ecd[e], x_y + mt.y_edge_c[e]);
+          acc += col_dot(model + mt.mo[E_JXG][e], d, mt.egd[e], x_z + mt.z_edge[e]);
+        }
+        const int at = mt.x_state[i] + d;
+        y_x[at] += acc + r1[at] * x_x[at];
+      } else if (r < 2 * n) { // dynamics rows of y_y
+        const int d = r - n;
+        double acc = -xs[d];
+        if (ine >= 0) {
+          const int e = ine, pa = mt.parent[e];
+          acc += row_dot(model + mt.mo[E_A][e], d, n, mt.sd[pa], x_x + mt.x_state[pa]);
+          acc += row_dot(model + mt.mo[E_B][e], d, n, mt.cd[e], x_x + mt.x_control[e]);
+        }
+        const int at = mt.y_dyn[i] + d;
+        y_y[at] += acc - r2[at] * x_y[at];
+      } else if (r < 2 * n + c) {
+        const int k = r - 2 * n, at = mt.y_node_c[i] + k;
+        y_y[at] += row_dot(model + mt.mo[N_JC][i], k, c, n, xs) - r2[at] * x_y[at];
+      } else {
+        const int k = r - 2 * n - c, at = mt.z_node[i] + k;
+        y_z[at] += row_dot(model + mt.mo[N_JG][i], k, g, n, xs) - (w[at] + r3[at]) * x_z[at];
+      }
+    }
+  } else {
+    const int e = item - mt.N, pa = mt.parent[e], ch = mt.child[e];
+    const int n = mt.sd[pa], nc = mt.sd[ch], m = mt.cd[e], c = mt.ecd[e], g = mt.egd[e];
+    const double *xp = x_x + mt.x_state[pa], *ue = x_x + mt.x_control[e];
+    for (int r = tid; r < m + c + g; r += TPB) {
+      if (r < m) { // control rows of y_x
+        const int d = r;
+        double acc = col_dot(model + mt.mo[E_M][e], d, n, xp);
+        acc += row_dot(model + mt.mo[E_R][e], d, m, m, ue);
+        acc += col_dot(model + mt.mo[E_B][e], d, nc, x_y + mt.y_dyn[ch]);
+        acc += col_dot(model + mt.mo[E_JUC][e], d, c, x_y + mt.y_edge_c[e]);
+        acc += col_dot(model + mt.mo[E_JUG][e], d, g, x_z + mt.z_edge[e]);
+        const int at = mt.x_control[e] + d;
+        y_x[at] += acc + r1[at] * x_x[at];
+      } else if (r < m + c) {
+        const int k = r - m, at = mt.y_edge_c[e] + k;
+        const double acc = row_dot(model + mt.mo[E_JXC][e], k, c, n, xp) + row_dot(model + mt.mo[E_JUC][e], k, c, m, ue);
+        y_y[at] += acc - r2[at] * x_y[at];
+      } else {
+        const int k = r - m - c, at = mt.z_edge[e] + k;
+        const double acc = row_dot(model + mt.mo[E_JXG][e], k, g, n, xp) + row_dot(model + mt.mo[E_JUG][e], k, g, m, ue);
+        y_z[at] += acc - (w[at] + r3[at]) * x_z[at];
+      }
+    }
+  }
+}
+
+} // namespace kkt
+} // namespace sipamd

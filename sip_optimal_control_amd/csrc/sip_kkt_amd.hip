@@ -1,0 +1,487 @@
+// sip_kkt_amd.hip -- C ABI of the batched Newton-KKT step
+// (include/sip_kkt_amd.h) over csrc/kkt_kernels.hpp and the library's own LQR
+// entry points (include/sip_lqr_amd.h).
+#include "../../include/sip_kkt_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "generic_plan.hpp"
+#include "kkt_kernels.hpp"
+
+struct sip_kkt_plan {
+  int64_t batch = 0;
+  int device = 0;
+  int E = 0, N = 0, root = 0;
+  int input_status = SIP_KKT_INVALID_INPUT;
+  std::vector<int> sd, cd, ncd, ngd, ecd, egd, parents, children;
+  std::vector<int> voff[7];
+  std::vector<long> moff[sipamd::kkt::NUM_BLOCKS];
+  int x_dim = 0, y_dim = 0, z_dim = 0;
+  long model_len = 0;
+  // Riccati back end: packed chain plan or general tree plan
+  sip_lqr_plan *chain = nullptr;
+  sip_lqr_tree_plan *tree = nullptr;
+  long in0_len = 0, in1_len = 0, out_len = 0, gain_len = 0;
+  // byte offsets of the regions of d_work
+  size_t at_in0 = 0, at_in1 = 0, at_out = 0, at_gain = 0, at_inv = 0, at_reg = 0, at_lqr = 0, work_bytes = 0;
+  void *d_ints = nullptr, *d_longs = nullptr;
+  sipamd::kkt::Meta meta{};
+  std::string name;
+
+  ~sip_kkt_plan() {
+    if (chain)
+      sip_lqr_plan_destroy(chain);
+    if (tree)
+      sip_lqr_tree_plan_destroy(tree);
+    if (d_ints)
+      (void)hipFree(d_ints);
+    if (d_longs)
+      (void)hipFree(d_longs);
+  }
+};
+
+namespace {
+
+using sipamd::kkt::Meta;
+
+std::vector<int> dims_or_zero(const int *src, int count) {
+  return src ? std::vector<int>(src, src + count) : std::vector<int>((size_t)count, 0);
+}
+
+// validate_input, types.cpp:68-127 without the in-degree / reachability part,
+// which the LQR traversal (lqr.cpp:563-631) latches.
+bool validate(const sip_kkt_plan &p, bool have_topology) {
+  for (int i = 0; i < p.N; ++i)
+    if (p.sd[i] < 0 || p.ncd[i] < 0 || p.ngd[i] < 0)
+      return false;
+  for (int e = 0; e < p.E; ++e)
+    if (p.cd[e] < 0 || p.ecd[e] < 0 || p.egd[e] < 0)
+      return false;
+  if (!have_topology || p.root < 0 || p.root >= p.N)
+    return false;
+  for (int e = 0; e < p.E; ++e) {
+    const int a = p.parents[e], c = p.children[e];
+    if (a < 0 || a >= p.N || c < 0 || c >= p.N || a == c)
+      return false;
+  }
+  return true;
+}
+
+bool is_uniform_chain(const sip_kkt_plan &p) {
+  if (p.E < 1 || p.root != 0 || p.sd[0] < 1 || p.cd[0] < 1)
+    return false;
+  for (int e = 0; e < p.E; ++e)
+    if (p.parents[e] != e || p.children[e] != e + 1 || p.cd[e] != p.cd[0])
+      return false;
+  for (int i = 0; i < p.N; ++i)
+    if (p.sd[i] != p.sd[0])
+      return false;
+  return true;
+}
+
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+int report(hipError_t e, const char *what) {
+  if (e == hipSuccess)
+    return SIP_LQR_OK;
+  std::fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e));
+  return SIP_LQR_ERR_HIP;
+}
+
+struct Regions {
+  double *in0, *in1, *out, *gain, *inv;
+  int *reg;
+  void *lqr;
+};
+Regions regions(const sip_kkt_plan *p, void *work) {
+  char *w = (char *)work;
+  Regions r;
+  r.in0 = (double *)(w + p->at_in0), r.in1 = (double *)(w + p->at_in1);
+  r.out = (double *)(w + p->at_out), r.gain = (double *)(w + p->at_gain);
+  r.inv = (double *)(w + p->at_inv), r.reg = (int *)(w + p->at_reg), r.lqr = w + p->at_lqr;
+  return r;
+}
+
+unsigned item_grid(const sip_kkt_plan *p) { return (unsigned)(p->batch * (p->N + p->E)); }
+
+hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double *model, const double *w,
+                           const double *r1, const double *r2, const double *r3, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(r.reg, 0, (size_t)p->batch * sizeof(int), s);
+  if (e != hipSuccess)
+    return e;
+  const long per = (long)p->y_dim + p->z_dim;
+  if (per > 0)
+    hipLaunchKernelGGL(sipamd::kkt::weights_kernel, dim3((unsigned)((p->batch * per + 255) / 256)), dim3(256), 0, s,
+                       p->meta, w, r2, r3, r.inv, r.reg, (long)p->batch);
+  hipLaunchKernelGGL(sipamd::kkt::condense_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta, model,
+                     r1, r.inv, r.in0, (long)p->batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_merge(const sip_kkt_plan *p, const Regions &r, int32_t *status, hipStream_t s) {
+  hipLaunchKernelGGL(sipamd::kkt::merge_status_kernel, dim3((unsigned)((p->batch + 255) / 256)), dim3(256), 0, s,
+                     r.reg, status, (long)p->batch, (int)SIP_KKT_NONPOSITIVE_REGULARIZATION);
+  return hipGetLastError();
+}
+
+hipError_t launch_rhs(const sip_kkt_plan *p, const Regions &r, const double *model, const double *b,
+                      const int32_t *status, hipStream_t s) {
+  hipLaunchKernelGGL(sipamd::kkt::rhs_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta, model, b,
+                     r.inv, r.in1, status, (long)p->batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_recover(const sip_kkt_plan *p, const Regions &r, const double *model, const double *b,
+                          double *sol, const int32_t *status, hipStream_t s) {
+  hipLaunchKernelGGL(sipamd::kkt::recover_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta, model,
+                     b, r.inv, r.out, sol, status, (long)p->batch);
+  return hipGetLastError();
+}
+
+int fill_status(const sip_kkt_plan *p, int32_t *d_status, hipStream_t s) {
+  std::vector<int32_t> st((size_t)p->batch, p->input_status);
+  if (hipMemcpyAsync(d_status, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return SIP_LQR_ERR_HIP;
+  return SIP_LQR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_parents,
+                        const int *edge_children, const int *state_dims, const int *control_dims,
+                        const int *node_c_dims, const int *node_g_dims, const int *edge_c_dims,
+                        const int *edge_g_dims, int device, sip_kkt_plan **out) {
+  if (out == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (batch < 1 || num_edges < 0 || state_dims == nullptr || (num_edges > 0 && control_dims == nullptr))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sip_kkt_plan *p = new (std::nothrow) sip_kkt_plan;
+  if (p == nullptr)
+    return SIP_LQR_ERR_ALLOC;
+  const int E = num_edges, N = E + 1;
+  p->batch = batch, p->device = device, p->E = E, p->N = N, p->root = root;
+  p->sd.assign(state_dims, state_dims + N);
+  p->cd = dims_or_zero(control_dims, E);
+  p->ncd = dims_or_zero(node_c_dims, N), p->ngd = dims_or_zero(node_g_dims, N);
+  p->ecd = dims_or_zero(edge_c_dims, E), p->egd = dims_or_zero(edge_g_dims, E);
+  const bool have_topology = E == 0 || (edge_parents != nullptr && edge_children != nullptr);
+  p->parents = dims_or_zero(edge_parents, E), p->children = dims_or_zero(edge_children, E);
+  for (auto &v : p->voff)
+    v.assign(N, 0);
+  for (auto &v : p->moff)
+    v.assign(N, 0);
+  *out = p;
+  if (!validate(*p, have_topology)) {
+    p->name = "invalid input";
+    return SIP_LQR_OK; // latched (helpers.cpp:24-26)
+  }
+
+  // model arena: node i, then edge i
+  using namespace sipamd::kkt;
+  long at = 0;
+  for (int i = 0; i < N; ++i) {
+    const long n = p->sd[i];
+    p->moff[N_Q][i] = at, at += n * n;
+    p->moff[N_JC][i] = at, at += p->ncd[i] * n;
+    p->moff[N_JG][i] = at, at += p->ngd[i] * n;
+    if (i < E) {
+      const int e = i;
+      const long np = p->sd[p->parents[e]], nc = p->sd[p->children[e]], m = p->cd[e];
+      p->moff[E_Q][e] = at, at += np * np;
+      p->moff[E_M][e] = at, at += np * m;
+      p->moff[E_R][e] = at, at += m * m;
+      p->moff[E_A][e] = at, at += nc * np;
+      p->moff[E_B][e] = at, at += nc * m;
+      p->moff[E_JXC][e] = at, at += p->ecd[e] * np;
+      p->moff[E_JUC][e] = at, at += p->ecd[e] * m;
+      p->moff[E_JXG][e] = at, at += p->egd[e] * np;
+      p->moff[E_JUG][e] = at, at += p->egd[e] * m;
+    }
+  }
+  p->model_len = at;
+
+  // populate_workspace_metadata, types.cpp:24-64
+  int xo = 0, yo = 0, zo = 0;
+  for (int i = 0; i < N; ++i) {
+    p->voff[SIP_KKT_X_STATE][i] = xo;
+    if (i < E) {
+      xo += p->sd[i];
+      p->voff[SIP_KKT_X_CONTROL][i] = xo;
+      xo += p->cd[i];
+    }
+  }
+  xo = p->sd[E];
+  for (int e = 0; e < E; ++e)
+    xo += p->sd[e] + p->cd[e];
+  std::vector<int> y_is_dyn;
+  for (int i = 0; i < N; ++i) {
+    p->voff[SIP_KKT_Y_DYN][i] = yo, yo += p->sd[i];
+    p->voff[SIP_KKT_Y_NODE_C][i] = yo, yo += p->ncd[i];
+    y_is_dyn.insert(y_is_dyn.end(), (size_t)p->sd[i], 1);
+    y_is_dyn.insert(y_is_dyn.end(), (size_t)p->ncd[i], 0);
+  }
+  for (int e = 0; e < E; ++e) {
+    p->voff[SIP_KKT_Y_EDGE_C][e] = yo, yo += p->ecd[e];
+    y_is_dyn.insert(y_is_dyn.end(), (size_t)p->ecd[e], 0);
+  }
+  for (int i = 0; i < N; ++i)
+    p->voff[SIP_KKT_Z_NODE][i] = zo, zo += p->ngd[i];
+  for (int e = 0; e < E; ++e)
+    p->voff[SIP_KKT_Z_EDGE][e] = zo, zo += p->egd[e];
+  p->x_dim = xo, p->y_dim = yo, p->z_dim = zo;
+
+  // Riccati back end + the offsets of its arenas
+  sipamd::GenericPlan g; // host tables only
+  g.set_shape(E, root, p->sd.data(), p->cd.data());
+  g.parents = p->parents, g.children = p->children;
+  size_t lqr_bytes = 0;
+  int rc = SIP_LQR_OK;
+  if (is_uniform_chain(*p)) {
+    rc = sip_lqr_plan_create(SIP_LQR_F64, batch, E, p->sd[0], p->cd[0], device, &p->chain);
+    if (rc == SIP_LQR_OK) {
+      g.layout_chain(p->sd[0], p->cd[0], E);
+      p->in0_len = g.in0_len, p->in1_len = g.in1_len, p->out_len = g.out_len, p->gain_len = g.gain_len;
+      lqr_bytes = sip_lqr_workspace_bytes(p->chain);
+      p->name = std::string("chain:") + sip_lqr_kernel_name(p->chain);
+    }
+  } else {
+    rc = sip_lqr_tree_plan_create(batch, E, root, p->parents.data(), p->children.data(), p->sd.data(),
+                                  p->cd.data(), device, &p->tree);
+    if (rc == SIP_LQR_OK && sip_lqr_tree_topology_status(p->tree) != SIP_LQR_SUCCESS) {
+      p->input_status = sip_lqr_tree_topology_status(p->tree); // INVALID_TOPOLOGY, latched
+      p->name = "invalid topology";
+      return SIP_LQR_OK;
+    }
+    if (rc == SIP_LQR_OK) {
+      g.layout_tree_native();
+      p->in0_len = g.in0_len, p->in1_len = 0, p->out_len = g.out_len, p->gain_len = 0;
+      lqr_bytes = sip_lqr_tree_work_len(p->tree) * sizeof(double) * (size_t)batch;
+      p->name = "tree:general";
+    }
+  }
+  if (rc != SIP_LQR_OK) {
+    delete p;
+    *out = nullptr;
+    return rc;
+  }
+  size_t cur = 0;
+  const size_t B = (size_t)batch * sizeof(double);
+  p->at_in0 = cur, cur = align256(cur + B * (size_t)p->in0_len);
+  p->at_in1 = p->chain ? cur : p->at_in0; // the tree arena holds q, r, c too
+  if (p->chain)
+    cur = align256(cur + B * (size_t)p->in1_len);
+  p->at_out = cur, cur = align256(cur + B * (size_t)p->out_len);
+  p->at_gain = cur, cur = align256(cur + B * (size_t)p->gain_len);
+  p->at_inv = cur, cur = align256(cur + B * (size_t)(p->y_dim + p->z_dim));
+  p->at_reg = cur, cur = align256(cur + (size_t)batch * sizeof(int));
+  p->at_lqr = cur, cur = align256(cur + lqr_bytes);
+  p->work_bytes = cur;
+  if (!p->chain)
+    p->in1_len = p->in0_len; // per-problem stride of the arena rhs_kernel writes
+
+  // incoming edge of every node (the root has none); child CSR as the LQR compiles it
+  std::vector<int> in_edge(N, -1), child_offsets(N + 1, 0), child_edges(E, 0);
+  for (int e = 0; e < E; ++e)
+    in_edge[p->children[e]] = e, ++child_offsets[p->parents[e] + 1];
+  for (int i = 0; i < N; ++i)
+    child_offsets[i + 1] += child_offsets[i];
+  {
+    std::vector<int> cursor(child_offsets.begin(), child_offsets.end() - 1);
+    for (int e = 0; e < E; ++e)
+      child_edges[cursor[p->parents[e]]++] = e; // stable in the edge index (lqr.cpp:588-598)
+  }
+
+  std::vector<int> ints;
+  auto pi = [&](const std::vector<int> &v) {
+    const size_t where = ints.size();
+    ints.insert(ints.end(), v.begin(), v.end());
+    return where;
+  };
+  const size_t a_sd = pi(p->sd), a_cd = pi(p->cd), a_ncd = pi(p->ncd), a_ngd = pi(p->ngd), a_ecd = pi(p->ecd),
+               a_egd = pi(p->egd), a_pa = pi(p->parents), a_ch = pi(p->children), a_in = pi(in_edge),
+               a_co = pi(child_offsets), a_ce = pi(child_edges), a_dyn = pi(y_is_dyn);
+  size_t a_v[7];
+  for (int t = 0; t < 7; ++t)
+    a_v[t] = pi(p->voff[t]);
+  std::vector<long> longs;
+  auto pl = [&](const std::vector<long> &v) {
+    const size_t where = longs.size();
+    longs.insert(longs.end(), v.begin(), v.end());
+    return where;
+  };
+  size_t a_m[NUM_BLOCKS];
+  for (int b = 0; b < NUM_BLOCKS; ++b)
+    a_m[b] = pl(p->moff[b]);
+  const std::vector<long> *lq[12] = {&g.oQ, &g.od, &g.oq, &g.oc, &g.ox, &g.oy, &g.oA, &g.oB, &g.oM, &g.oR, &g.orr, &g.ou};
+  size_t a_l[12];
+  for (int t = 0; t < 12; ++t)
+    a_l[t] = pl(*lq[t]);
+
+  hipError_t he = hipSetDevice(device);
+  if (he == hipSuccess)
+    he = hipMalloc(&p->d_ints, std::max<size_t>(1, ints.size()) * sizeof(int));
+  if (he == hipSuccess)
+    he = hipMalloc(&p->d_longs, std::max<size_t>(1, longs.size()) * sizeof(long));
+  if (he == hipSuccess)
+    he = hipMemcpy(p->d_ints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (he == hipSuccess)
+    he = hipMemcpy(p->d_longs, longs.data(), longs.size() * sizeof(long), hipMemcpyHostToDevice);
+  if (he != hipSuccess) {
+    std::fprintf(stderr, "sip_kkt_plan_create: HIP error: %s\n", hipGetErrorString(he));
+    delete p;
+    *out = nullptr;
+    return SIP_LQR_ERR_HIP;
+  }
+  const int *di = (const int *)p->d_ints;
+  const long *dl = (const long *)p->d_longs;
+  Meta &m = p->meta;
+  m.E = E, m.N = N, m.root = root, m.x_dim = p->x_dim, m.y_dim = p->y_dim, m.z_dim = p->z_dim;
+  m.model_len = p->model_len, m.in0_len = p->in0_len, m.in1_len = p->in1_len, m.out_len = p->out_len;
+  m.sd = di + a_sd, m.cd = di + a_cd, m.ncd = di + a_ncd, m.ngd = di + a_ngd, m.ecd = di + a_ecd, m.egd = di + a_egd;
+  m.parent = di + a_pa, m.child = di + a_ch, m.in_edge = di + a_in;
+  m.child_offsets = di + a_co, m.child_edges = di + a_ce, m.y_is_dyn = di + a_dyn;
+  m.x_state = di + a_v[0], m.x_control = di + a_v[1], m.y_dyn = di + a_v[2], m.y_node_c = di + a_v[3];
+  m.y_edge_c = di + a_v[4], m.z_node = di + a_v[5], m.z_edge = di + a_v[6];
+  for (int b = 0; b < NUM_BLOCKS; ++b)
+    m.mo[b] = dl + a_m[b];
+  const long **dst[12] = {&m.oQ, &m.od, &m.oq, &m.oc, &m.ox, &m.oy, &m.oA, &m.oB, &m.oM, &m.oR, &m.orr, &m.ou};
+  for (int t = 0; t < 12; ++t)
+    *dst[t] = dl + a_l[t];
+  p->input_status = SIP_KKT_SUCCESS;
+  return SIP_LQR_OK;
+}
+
+void sip_kkt_plan_destroy(sip_kkt_plan *plan) { delete plan; }
+
+int sip_kkt_input_status(const sip_kkt_plan *p) { return p ? p->input_status : SIP_KKT_INVALID_INPUT; }
+
+size_t sip_kkt_len(const sip_kkt_plan *p, int which) {
+  if (p == nullptr || p->input_status != SIP_KKT_SUCCESS)
+    return 0;
+  switch (which) {
+  case SIP_KKT_LEN_X: return (size_t)p->x_dim;
+  case SIP_KKT_LEN_Y: return (size_t)p->y_dim;
+  case SIP_KKT_LEN_Z: return (size_t)p->z_dim;
+  case SIP_KKT_LEN_MODEL: return (size_t)p->model_len;
+  default: return 0;
+  }
+}
+
+size_t sip_kkt_model_offset(const sip_kkt_plan *p, int block, int index) {
+  if (p == nullptr || p->input_status != SIP_KKT_SUCCESS || block < 0 || block >= SIP_KKT_NUM_BLOCKS ||
+      index < 0 || index >= (block <= SIP_KKT_NODE_DG_DX ? p->N : p->E))
+    return (size_t)-1;
+  return (size_t)p->moff[block][index];
+}
+
+size_t sip_kkt_vector_offset(const sip_kkt_plan *p, int table, int index) {
+  if (p == nullptr || p->input_status != SIP_KKT_SUCCESS || table < 0 || table > SIP_KKT_Z_EDGE || index < 0)
+    return (size_t)-1;
+  const bool per_edge = table == SIP_KKT_X_CONTROL || table == SIP_KKT_Y_EDGE_C || table == SIP_KKT_Z_EDGE;
+  if (index >= (per_edge ? p->E : p->N))
+    return (size_t)-1;
+  return (size_t)p->voff[table][index];
+}
+
+size_t sip_kkt_work_bytes(const sip_kkt_plan *p) {
+  return (p && p->input_status == SIP_KKT_SUCCESS) ? p->work_bytes : 0;
+}
+
+const char *sip_kkt_kernel_name(const sip_kkt_plan *p) { return p ? p->name.c_str() : ""; }
+
+int sip_kkt_factor(const sip_kkt_plan *p, const double *d_model, const double *d_w, const double *d_r1,
+                   const double *d_r2, const double *d_r3, void *d_work, int32_t *d_status, void *stream) {
+  if (p == nullptr || d_status == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  if (p->input_status != SIP_KKT_SUCCESS)
+    return fill_status(p, d_status, s);
+  if ((!d_model && p->model_len > 0) || (!d_w && p->z_dim > 0) || (!d_r1 && p->x_dim > 0) ||
+      (!d_r2 && p->y_dim > 0) || (!d_r3 && p->z_dim > 0) || !d_work)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  const Regions r = regions(p, d_work);
+  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, s);
+  if (e != hipSuccess)
+    return report(e, "sip_kkt_factor(condense)");
+  const int rc = p->chain ? sip_lqr_factor(p->chain, r.in0, r.gain, d_status, r.lqr, s)
+                          : sip_lqr_tree_factor(p->tree, r.in0, (double *)r.lqr, d_status, s);
+  if (rc != SIP_LQR_OK)
+    return rc;
+  return report(launch_merge(p, r, d_status, s), "sip_kkt_factor(status)");
+}
+
+int sip_kkt_solve(const sip_kkt_plan *p, const double *d_model, const double *d_b, double *d_sol, void *d_work,
+                  const int32_t *d_status, void *stream) {
+  if (p == nullptr || d_status == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (p->input_status != SIP_KKT_SUCCESS)
+    return SIP_LQR_OK; // nothing was factored; solve() after a false factor() is undefined in the reference
+  const long kkt = (long)p->x_dim + p->y_dim + p->z_dim;
+  if ((!d_model && p->model_len > 0) || (kkt > 0 && (!d_b || !d_sol)) || !d_work)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const Regions r = regions(p, d_work);
+  hipError_t e = launch_rhs(p, r, d_model, d_b, d_status, s);
+  if (e != hipSuccess)
+    return report(e, "sip_kkt_solve(rhs)");
+  const int rc = p->chain ? sip_lqr_solve(p->chain, r.in0, r.in1, r.out, r.gain, r.lqr, s)
+                          : sip_lqr_tree_solve(p->tree, r.in0, (double *)r.lqr, r.out, d_status, s);
+  if (rc != SIP_LQR_OK)
+    return rc;
+  return report(launch_recover(p, r, d_model, d_b, d_sol, d_status, s), "sip_kkt_solve(recover)");
+}
+
+int sip_kkt_factor_solve(const sip_kkt_plan *p, const double *d_model, const double *d_w, const double *d_r1,
+                         const double *d_r2, const double *d_r3, const double *d_b, double *d_sol, void *d_work,
+                         int32_t *d_status, void *stream) {
+  if (p == nullptr || d_status == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (p->input_status != SIP_KKT_SUCCESS || p->chain == nullptr) {
+    const int rc = sip_kkt_factor(p, d_model, d_w, d_r1, d_r2, d_r3, d_work, d_status, stream);
+    return rc != SIP_LQR_OK ? rc : sip_kkt_solve(p, d_model, d_b, d_sol, d_work, d_status, stream);
+  }
+  const long kkt = (long)p->x_dim + p->y_dim + p->z_dim;
+  if (!d_model || (!d_w && p->z_dim > 0) || !d_r1 || !d_r2 || (!d_r3 && p->z_dim > 0) || !d_work ||
+      (kkt > 0 && (!d_b || !d_sol)))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const Regions r = regions(p, d_work);
+  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, s);
+  if (e == hipSuccess)
+    e = launch_rhs(p, r, d_model, d_b, nullptr, s);
+  if (e != hipSuccess)
+    return report(e, "sip_kkt_factor_solve(condense)");
+  const int rc = sip_lqr_factor_solve(p->chain, r.in0, r.in1, r.out, r.gain, d_status, r.lqr, s);
+  if (rc != SIP_LQR_OK)
+    return rc;
+  e = launch_merge(p, r, d_status, s);
+  if (e == hipSuccess)
+    e = launch_recover(p, r, d_model, d_b, d_sol, d_status, s);
+  return report(e, "sip_kkt_factor_solve(recover)");
+}
+
+int sip_kkt_add_Kx_to_y(const sip_kkt_plan *p, const double *d_model, const double *d_w, const double *d_r1,
+                        const double *d_r2, const double *d_r3, const double *d_x, double *d_y, void *stream) {
+  if (p == nullptr || p->input_status != SIP_KKT_SUCCESS)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  const long kkt = (long)p->x_dim + p->y_dim + p->z_dim;
+  if (kkt == 0)
+    return SIP_LQR_OK;
+  if ((!d_model && p->model_len > 0) || (!d_w && p->z_dim > 0) || (!d_r1 && p->x_dim > 0) ||
+      (!d_r2 && p->y_dim > 0) || (!d_r3 && p->z_dim > 0) || !d_x || !d_y)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, (hipStream_t)stream,
+                     p->meta, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
+  return report(hipGetLastError(), "sip_kkt_add_Kx_to_y");
+}
+
+} // extern "C"

@@ -24,7 +24,7 @@ def _declared_functions():
     for header in glob.glob(os.path.join(ROOT, "include", "*.h")):
         text = open(header).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names.update(re.findall(r"\b(sip_lqr_\w+)\s*\(", text))
+        names.update(re.findall(r"\b(sip_(?:lqr|kkt)_\w+)\s*\(", text))
     return names
 
 

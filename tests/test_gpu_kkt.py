@@ -1,0 +1,188 @@
+"""GPU parity of the batched Newton-KKT step (include/sip_kkt_amd.h) against
+the CPU oracle (oracle/kkt_oracle.c) and the reference's own property
+(tests/variable_dimensions_test.cpp:135-181: K * solution == rhs to 1e-9).
+
+Tolerance: fp64 on both sides; the GPU accumulates each output element in the
+reference's order but with fused multiply-adds, the oracle without
+(-ffp-contract=off): agreement is required to 1e-9 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.kkt import KKTOracle, dense_kkt_matrix
+from tests import reference_kkt_problems as rk
+
+pytestmark = pytest.mark.gpu
+REL = 1e-9
+
+
+def _make(dims, batch):
+    from sip_optimal_control_amd import BatchedNewtonKKT
+    return BatchedNewtonKKT(dims.parents, dims.children, dims.sd, dims.cd, dims.ncd, dims.ngd, dims.ecd, dims.egd,
+                            batch=batch, root=dims.root)
+
+
+def _dev(*arrays):
+    return [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda() for a in arrays]
+
+
+def _batchify(batch, *arrays):
+    """batch copies with a problem-dependent scaling so that problems differ."""
+    out = []
+    for a in arrays:
+        out.append(np.stack([a * (1.0 + 0.01 * p) for p in range(batch)]))
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(rk.REFERENCE_CASES))
+def test_reference_cases(name):
+    dims, model, (w, r1, r2, r3, rhs) = rk.reference_case(name)
+    batch = 3
+    model_b, w_b, r1_b, r2_b, r3_b, rhs_b = _batchify(batch, model, w, r1, r2, r3, rhs)
+    kkt = _make(dims, batch)
+    assert (kkt.x_dim, kkt.y_dim, kkt.z_dim, kkt.model_len) == (dims.x_dim, dims.y_dim, dims.z_dim, dims.model_len)
+    assert kkt.kernel_name == "tree:general"
+    d = _dev(model_b, w_b, r1_b, r2_b, r3_b, rhs_b)
+    status = kkt.factor(*d[:5])
+    assert status.cpu().tolist() == [0] * batch
+    sol = kkt.solve(d[0], d[5])
+    prod = kkt.add_Kx_to_y(*d[:5], sol).cpu().numpy()
+    sol = sol.cpu().numpy()
+    o = KKTOracle(dims)
+    for p in range(batch):
+        assert o.factor(model_b[p], w_b[p], r1_b[p], r2_b[p], r3_b[p]) == 0
+        ref = o.solve(model_b[p], rhs_b[p])
+        assert np.abs(sol[p] - ref).max() <= REL * max(1.0, np.abs(ref).max())
+        assert np.linalg.norm(prod[p] - rhs_b[p]) < 1e-9  # the reference's own tolerance
+        K = dense_kkt_matrix(dims, model_b[p], w_b[p], r1_b[p], r2_b[p], r3_b[p])
+        np.testing.assert_allclose(prod[p], K @ sol[p], rtol=0, atol=1e-12)
+    # the fused entry point gives the same answer
+    sol2, status2 = kkt.factor_solve(*d)
+    assert status2.cpu().tolist() == [0] * batch
+    np.testing.assert_allclose(sol2.cpu().numpy(), sol, rtol=1e-12, atol=1e-13)
+    # second right-hand side on the same factorization (tests/lqr_test.cpp:431-450 style)
+    kkt.factor(*d[:5])
+    rhs2 = np.cos(np.arange(batch * dims.kkt_dim)).reshape(batch, -1)
+    sol3 = kkt.solve(d[0], _dev(rhs2)[0]).cpu().numpy()
+    for p in range(batch):
+        ref = o.solve(model_b[p], rhs2[p])
+        assert np.abs(sol3[p] - ref).max() <= REL * max(1.0, np.abs(ref).max())
+
+
+def test_offsets_match_the_reference_ordering():
+    dims, _, _ = rk.reference_case("chain_node_edge_constraints")
+    kkt = _make(dims, 1)
+    from sip_optimal_control_amd.kkt import EDGE_BLOCKS, NODE_BLOCKS, VECTOR_TABLES
+    for t, name in enumerate(VECTOR_TABLES):
+        count = dims.E if name in ("x_control", "y_edge_c", "z_edge") else dims.N
+        assert [kkt.vector_offset(t, i) for i in range(count)] == dims.off[name][:count]
+        with pytest.raises(IndexError):
+            kkt.vector_offset(t, count)
+    for b, name in enumerate(NODE_BLOCKS):
+        assert [kkt.model_offset(b, i) for i in range(dims.N)] == dims.node_off[name]
+    for b, name in enumerate(EDGE_BLOCKS):
+        assert [kkt.model_offset(len(NODE_BLOCKS) + b, e) for e in range(dims.E)] == dims.edge_off[name]
+
+
+@pytest.mark.parametrize("n,m,T,batch", [(4, 2, 16, 64), (12, 4, 50, 32), (8, 3, 20, 16), (6, 2, 12, 8)])
+def test_newton_kkt_benchmark_shapes(n, m, T, batch):
+    """Uniform chains (benchmarks/newton_kkt_benchmark.cpp:58-83): packed chain layout, fused
+    kernels where the shape has one (12,4 / 4,2 / 8,3), the general engine otherwise (6,2)."""
+    dims = rk.newton_kkt_dims(n, m, T)
+    arrays = rk.newton_kkt_problem(dims, seed=100 * n + m, batch=batch, r2_max=1e2)
+    kkt = _make(dims, batch)
+    assert kkt.kernel_name.startswith("chain:")
+    d = _dev(*arrays)
+    sol, status = kkt.factor_solve(*d)
+    assert status.cpu().tolist() == [0] * batch
+    sol = sol.cpu().numpy()
+    o = KKTOracle(dims)
+    ref, ref_status = o.batch(*arrays, threads=4)
+    assert ref_status.tolist() == [0] * batch
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert (np.abs(sol - ref) / scale).max() <= REL
+    # split entry points agree with the fused one
+    kkt.factor(*d[:5])
+    sol_split = kkt.solve(d[0], d[5]).cpu().numpy()
+    assert (np.abs(sol_split - ref) / scale).max() <= REL
+    # K * sol == rhs through the GPU operator
+    prod = kkt.add_Kx_to_y(*d[:5], _dev(sol)[0]).cpu().numpy()
+    for p in (0, batch - 1):
+        K = dense_kkt_matrix(dims, *[a[p] for a in arrays[:5]])
+        bound = 1e-9 * np.linalg.norm(K, np.inf) * np.abs(sol[p]).max()
+        assert np.abs(prod[p] - arrays[5][p]).max() <= bound
+        np.testing.assert_allclose(prod[p], K @ sol[p], rtol=0, atol=bound)
+
+
+def test_full_benchmark_regularization_range():
+    """r2 log-uniform in [1e-3, 1e9] as the benchmark draws it (:249-262): compare with the oracle."""
+    dims = rk.newton_kkt_dims(12, 4, 50)
+    batch = 16
+    arrays = rk.newton_kkt_problem(dims, seed=3, batch=batch)
+    kkt = _make(dims, batch)
+    sol, status = kkt.factor_solve(*_dev(*arrays))
+    ref, ref_status = KKTOracle(dims).batch(*arrays, threads=4)
+    assert status.cpu().tolist() == ref_status.tolist() == [0] * batch
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert (np.abs(sol.cpu().numpy() - ref) / scale).max() <= 1e-8
+
+
+def test_false_paths_and_status_codes():
+    dims = rk.newton_kkt_dims(4, 2, 6)
+    batch = 6
+    model, w, r1, r2, r3, rhs = rk.newton_kkt_problem(dims, seed=11, batch=batch, r2_max=1e2)
+    r2[1, dims.off["y_edge_c"][2]] = 0.0          # helpers.cpp:281-286
+    r2[2, dims.off["y_dyn"][3] + 1] = -2.0        # helpers.cpp:256-261
+    w[3, dims.off["z_edge"][1]] = -r3[3, dims.off["z_edge"][1]]  # w + r3 == 0, :289-296
+    nodes, edges = dims.unpack_model(model[4])
+    edges[1]["d2L_du2"] = -5.0 * np.eye(dims.cd[1])  # G not positive definite -> G_FACTORIZATION_FAILURE
+    model[4] = dims.pack_model(nodes, edges)
+    kkt = _make(dims, batch)
+    d = _dev(model, w, r1, r2, r3, rhs)
+    sentinel = torch.full((batch, dims.kkt_dim), 7.0, dtype=torch.float64, device="cuda")
+    sol, status = kkt.factor_solve(*d, sol=sentinel.clone())
+    ref, ref_status = KKTOracle(dims).batch(model, w, r1, r2, r3, rhs)
+    assert status.cpu().tolist() == ref_status.tolist() == [0, 5, 5, 5, 3, 0]
+    sol = sol.cpu().numpy()
+    for p in range(batch):
+        if ref_status[p] == 0:
+            assert np.abs(sol[p] - ref[p]).max() <= REL * np.abs(ref[p]).max()
+        else:
+            assert (sol[p] == 7.0).all()  # untouched
+    # split path reports the same statuses
+    assert kkt.factor(*d[:5]).cpu().tolist() == [0, 5, 5, 5, 3, 0]
+
+
+def test_invalid_input_is_latched():
+    from sip_optimal_control_amd import BatchedNewtonKKT
+    kkt = BatchedNewtonKKT([0, 0], [1, 2], [2, 1, 3], [1, 2], edge_c_dims=[-1, 1], batch=2)
+    assert kkt.input_status == 6 and kkt.kkt_dim == 0
+    assert kkt.factor(None, None, None, None, None).cpu().tolist() == [6, 6]
+    dag = BatchedNewtonKKT([0, 1], [2, 2], [2, 1, 3], [1, 2], batch=2)  # variable_dimensions_test.cpp:210-214
+    assert dag.input_status == 4
+    assert dag.factor(None, None, None, None, None).cpu().tolist() == [4, 4]
+
+
+def test_null_constraint_dims_and_single_node():
+    from sip_optimal_control_amd import BatchedNewtonKKT
+    dims = rk.KKTDims([0, 1], [1, 2], [2, 1, 3], [1, 2])
+    model = rk.initialize_model(dims)
+    w, r1, r2, r3, rhs = rk.regularization(dims)
+    kkt = BatchedNewtonKKT(dims.parents, dims.children, dims.sd, dims.cd, batch=1)
+    assert kkt.z_dim == 0
+    d = _dev(model[None], r1[None], r2[None], rhs[None])
+    sol, status = kkt.factor_solve(d[0], None, d[1], d[2], None, d[3])
+    o = KKTOracle(dims)
+    assert o.factor(model, w, r1, r2, r3) == 0 and status.cpu().tolist() == [0]
+    np.testing.assert_allclose(sol.cpu().numpy()[0], o.solve(model, rhs), rtol=1e-10, atol=1e-12)
+    # one node, no edges: x = -(Q + r1 + ...)^-1-type solve through the root formulas
+    one = rk.KKTDims([], [], [3], [], node_c=[1], node_g=[2])
+    model1 = rk.initialize_model(one)
+    w1, r11, r21, r31, rhs1 = rk.regularization(one)
+    k1 = BatchedNewtonKKT([], [], [3], [], [1], [2], batch=1)
+    d1 = _dev(model1[None], w1[None], r11[None], r21[None], r31[None], rhs1[None])
+    sol1, st1 = k1.factor_solve(*d1)
+    K = dense_kkt_matrix(one, model1, w1, r11, r21, r31)
+    assert st1.cpu().tolist() == [0]
+    np.testing.assert_allclose(sol1.cpu().numpy()[0], np.linalg.solve(K, rhs1), rtol=1e-9, atol=1e-11)
