@@ -21,11 +21,18 @@
 // NumericalIssue condition; statuses follow lqr.hpp:68-74 in the reference's
 // order (G before delta before F at a node; first failing node in postorder).
 //
-// The forward rollout (lqr.cpp:821-870) is restated with the identities
-//   y_c = g_c + W_c z,  x_c = z + c_c - delta_c o y_c,  z = A x + B u,
-// (g_c = v_c - W_c(delta_c o v_c - c_c) is the reference's own `g`,
-// lqr.cpp:778-781; the second line is the dynamics row of the KKT system),
-// so the only factor state spilled per node is [W | g].
+// The forward rollout (lqr.cpp:821-870) is restated on S = F^{-1} (the inverse
+// that compute_regularized_W forms, lqr.cpp:516-519) with z = A x + B u and
+// zeta = D^{-1/2} z:
+//   x_c = (I + Delta V)^{-1} (z + c - delta o v) = D^{1/2} (S zeta + h),
+//   y_c = g_c + W_c z                            = g_c + D^{-1/2} (zeta - S zeta),
+// where g_c = v_c - W_c(delta_c o v_c - c_c) is the reference's own `g`
+// (lqr.cpp:778-781) and h = S D^{-1/2} (c_c - delta_c o v_c) is one more
+// right-hand side of the F solve of the node (carried by the vector lane), so
+// the factor state spilled per node is [S | g | h].  Both lines are the
+// reference's formulas (F_inv_mult_vector, lqr.cpp:531-549; W of
+// lqr.cpp:521-528) and keep their accuracy for delta anywhere in
+// [1e-8, 1e9]: the cheaper x_c = z + c - delta o y_c cancels for large delta.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -135,15 +142,18 @@ struct ChainLayout {
   static constexpr int VNODE = 2 * N;                  // q | c   (x | y)
   static constexpr int VEDGE = M;                      // r       (u)
   static constexpr int GAIN = M * N + M;               // K | k
-  static constexpr int WSN = N * N + N;                // W | g   (workspace)
+  static constexpr int WSN = N * N + 2 * N;            // S | g | h (workspace)
 };
 
 // F_factor / W of one node (lqr.cpp:487-529).  V: column c of V (lanes < N).
-// dl: delta_c one per lane (1.0 on lanes >= N).  Returns pivot failure.
+// dl: delta_c one per lane (1.0 on lanes >= N).  tv: c - delta o v on the
+// vector lane, zeros elsewhere.  X returns S = F^{-1} (lanes < N) and, on the
+// vector lane, S D^{-1/2} tv.  Returns pivot failure.
 template <int N>
 __device__ __forceinline__ bool node_factor(const double (&V)[N], const double dl,
                                             const int c, const double (&E)[N],
-                                            double (&W)[N]) {
+                                            const double (&tv)[N], double (&W)[N],
+                                            double (&X)[N]) {
   const double sdi = rsqrt_nr(dl); // sqrt_delta_inv, lqr.cpp:482
   const double sd = dl * sdi;      // sqrt_delta,     lqr.cpp:481
   double S[N], A[N], rinv[N];
@@ -154,9 +164,9 @@ __device__ __forceinline__ bool node_factor(const double (&V)[N], const double d
     A[r] = __builtin_fma(S[r], V[r], E[r]); // I + D^1/2 V D^1/2, lqr.cpp:497-503
   });
   const bool fail = chol_ldl_dpp<N>(A, rinv, c); // LLT of lqr.cpp:505
-  double X[N];
   sfor<0, N>([&](auto ii) { X[decltype(ii)::value] = E[decltype(ii)::value]; });
-  ldl_solve_dpp<N>(A, rinv, X); // F^{-1}, lqr.cpp:516-519
+  spreadv<N, false>(X, sdi, tv); // vector lane: D^{-1/2} (c - delta o v), lqr.cpp:539-541
+  ldl_solve_dpp<N>(A, rinv, X); // F^{-1} [I | .], lqr.cpp:516-519, 542-545
   sfor<0, N>([&](auto ii) { S[decltype(ii)::value] = 0.0; });
   spread<N, false, true>(S, sdi, sdi);
   sfor<0, N>([&](auto ii) {
@@ -256,23 +266,21 @@ struct StageDma {
 template <int N, int M, bool WPACK>
 struct StagedCfg {
   using L = ChainLayout<N, M>;
-  static constexpr int WSN = // W | g, even number of scalars
-      WPACK ? ((N * (N + 1) / 2 + N + 1) / 2) * 2 : L::WSN;
+  static constexpr int WSN = // S | g | h, even number of scalars
+      WPACK ? ((N * (N + 1) / 2 + 2 * N + 1) / 2) * 2 : L::WSN;
   // backward: whole stage block of mats + of vecs
   using BM = StageDma<(L::NODE + L::EDGE) / 2>;
   using BV = StageDma<(L::VNODE + L::VEDGE) / 2>;
   static constexpr int B_BYTES = BM::BYTES + BV::BYTES;
-  // forward: A|B, gains, W|g of the child, c and delta of the child
+  // forward: A|B, gains, S|g|h of the child, delta of the child
   using FA = StageDma<(N * N + N * M) / 2>;
   using FG = StageDma<L::GAIN / 2>;
   using FW = StageDma<WSN / 2>;
   using FC = StageDma<N / 2>;
-  static constexpr int F_BYTES =
-      FA::BYTES + FG::BYTES + FW::BYTES + 2 * FC::BYTES;
+  static constexpr int F_BYTES = FA::BYTES + FG::BYTES + FW::BYTES + FC::BYTES;
   // LDS-DMA instructions per forward stage: the count the rollout's
   // `s_waitcnt vmcnt(F_GLDS)` relies on.
-  static constexpr int F_GLDS =
-      FA::INSTR + FG::INSTR + FW::INSTR + 2 * FC::INSTR;
+  static constexpr int F_GLDS = FA::INSTR + FG::INSTR + FW::INSTR + FC::INSTR;
   static constexpr int B_NBUF = 2; // backward: one stage ahead
 #ifndef SIP_LQR_FNBUF
 #define SIP_LQR_FNBUF 3
@@ -395,11 +403,20 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   auto load_tail = [&](auto nm, auto nv, NodeTail &nt) {
     const double d = nm[N * N + cm];
     nt.dl = isM ? d : 1.0;
-    sfor<0, N>([&](auto ii) {
-      constexpr int r = decltype(ii)::value;
-      nt.cv[r] = nv[N + r];
-      nt.dv[r] = nm[N * N + r];
-    });
+    if constexpr (std::is_same_v<decltype(nm), lds_cdouble *>) {
+      auto csrc = isV ? nv + N : zeros, dsrc = isV ? nm + N * N : zeros;
+      sfor<0, N>([&](auto ii) {
+        constexpr int r = decltype(ii)::value;
+        nt.cv[r] = csrc[r];
+        nt.dv[r] = dsrc[r];
+      });
+    } else {
+      sfor<0, N>([&](auto ii) {
+        constexpr int r = decltype(ii)::value;
+        nt.cv[r] = isV ? nv[N + r] : 0.0;
+        nt.dv[r] = isV ? nm[N * N + r] : 0.0;
+      });
+    }
   };
   auto finish_node = [&](const int i, const NodeTail &nt) {
     const double dl = nt.dl;
@@ -407,12 +424,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     const bool bad_row = ((bad >> (lane & 48)) & 0xffffull) != 0;
     if (stat == 0 && bad_row)
       stat = 1; // INVALID_DELTA
+    // c - delta o v on the vector lane, exact zeros elsewhere (cv = dv = 0)
+    double tv[N], X[N];
+    sfor<0, N>([&](auto ii) {
+      constexpr int r = decltype(ii)::value;
+      tv[r] = nt.cv[r] - nt.dv[r] * V[r];
+    });
     if constexpr (STAGED) {
-      double tv[N];
-      sfor<0, N>([&](auto ii) {
-        constexpr int r = decltype(ii)::value;
-        tv[r] = nt.cv[r] - nt.dv[r] * V[r];
-      });
       if (isV) {
         sfor<0, N>([&](auto ii) {
           constexpr int r = decltype(ii)::value;
@@ -423,15 +441,19 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     } else {
       sfor<0, N>([&](auto ii) {
         constexpr int r = decltype(ii)::value;
-        t[r] = nt.cv[r] - nt.dv[r] * V[r];
+        t[r] = tv[r];
         vch[r] = V[r];
       });
     }
     SIP_SEG(7);
-    const bool ffail = node_factor<N>(V, dl, c, E, W);
+    const bool ffail = node_factor<N>(V, dl, c, E, tv, W, X);
     SIP_SEG(8);
     if (stat == 0 && ffail)
       stat = 2; // F_FACTORIZATION_FAILURE
+    if (valid && isV) { // h = S D^{-1/2} (c - delta o v)
+      double *hn = pw + (long)i * WSN + WG + N;
+      sfor<0, N>([&](auto ii) { hn[decltype(ii)::value] = X[decltype(ii)::value]; });
+    }
     if constexpr (WPACK) {
       // Column c of the lower triangle (rows c..N-1), packed by columns.
       // Ragged and lane-dependent, so instead of 12 exec-masked stores the
@@ -441,13 +463,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
         constexpr int r = decltype(ii)::value;
         const int vo = (r >= c) ? wstore_base : 0x7ffff000;
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, W[r]), ws_rsrc, vo + r * 8,
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, X[r]), ws_rsrc, vo + r * 8,
                                               i * (WSN * 8), 0);
       });
     } else if (valid && isM) {
       double *wn = pw + (long)i * WSN + c * N;
       sfor<0, N>(
-          [&](auto ii) { wn[decltype(ii)::value] = W[decltype(ii)::value]; });
+          [&](auto ii) { wn[decltype(ii)::value] = X[decltype(ii)::value]; });
     }
   };
 
@@ -651,13 +673,11 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   typename C::FA dma_fa;
   typename C::FG dma_fg;
   typename C::FW dma_fw;
-  typename C::FC dma_fc;
-  typename C::FC dma_fd; // delta lives in mats: its own problem stride
+  typename C::FC dma_fd; // delta of the child node
   if constexpr (STAGED) {
     dma_fa.init(lane, (unsigned)(mats_len * 8), max_rel);
     dma_fg.init(lane, (unsigned)(gains_len * 8), max_rel);
     dma_fw.init(lane, (unsigned)(ws_len * 8), max_rel);
-    dma_fc.init(lane, (unsigned)(vecs_len * 8), max_rel);
     dma_fd.init(lane, (unsigned)(mats_len * 8), max_rel);
   }
   auto issue_forward = [&](const int i, lds_char *buf) {
@@ -667,11 +687,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
                  buf + C::FA::BYTES, lane);
     dma_fw.issue((const char *)(wsp + p0 * ws_len + (long)(i + 1) * WSN),
                  buf + C::FA::BYTES + C::FG::BYTES, lane);
-    dma_fc.template issue<SIP_LQR_NT_IN>((const char *)(vecs + p0 * vecs_len + (long)(i + 1) * VSTG + N),
-                 buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES, lane);
     dma_fd.template issue<SIP_LQR_NT_IN>(
         (const char *)(mats + p0 * mats_len + (long)(i + 1) * STG + N * N),
-        buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES + C::FC::BYTES, lane);
+        buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES, lane);
   };
   if constexpr (STAGED) {
     if (T > 0)
@@ -680,13 +698,15 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       issue_forward(1, lds + C::F_BYTES);
   }
 
+  // root (lqr.cpp:798-819): x_0 = -(I + Delta V)^{-1}(delta o v - c) = D^{1/2} h_0,
+  // y_0 = v_0 + V_0 x_0 = g_0
   double x, y;
   {
     const double gg = pw[WG + cm];
-    const double cc = pv[N + cm];
+    const double hh = pw[WG + N + cm];
     const double dd = pm[N * N + cm];
     y = gg;
-    x = cc - dd * gg;
+    x = (dd * rsqrt_nr(dd)) * hh;
     if (valid && isM) {
       ps[c] = x;
       ps[N + c] = y;
@@ -695,8 +715,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   int fbuf = 0; // LDS buffer of stage i = i % F_NBUF
   for (int i = 0; i < T; ++i) {
     double KT[N], Arow[N], Brow[M], Wc[N];
-    double kk0, gg, cc, dd;
-    auto read_stage = [&](auto em, auto gi, auto wn, auto cp, auto dp) {
+    double kk0, gg, hh, dd;
+    auto read_stage = [&](auto em, auto gi, auto wn, auto dp) {
       sfor<0, N>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         KT[k] = gi[k * M + cu];
@@ -709,7 +729,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       });
       kk0 = gi[N * M + cu];
       gg = wn[WG + cm];
-      cc = cp[cm];
+      hh = wn[WG + N + cm];
       dd = dp[cm];
     };
     SIP_STAMP(ts_a);
@@ -726,21 +746,20 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       SIP_STAMP(ts_b);
       acc_fwait += ts_b - ts_a;
       lds_char *b1 = buf + C::FA::BYTES, *b2 = b1 + C::FG::BYTES,
-               *b3 = b2 + C::FW::BYTES, *b4 = b3 + C::FC::BYTES;
+               *b3 = b2 + C::FW::BYTES;
       read_stage((lds_cdouble *)(buf + rr * ((N * N + N * M) * 8)),
                  (lds_cdouble *)(b1 + rr * (L::GAIN * 8)),
                  (lds_cdouble *)(b2 + rr * (WSN * 8)),
-                 (lds_cdouble *)(b3 + rr * (N * 8)),
-                 (lds_cdouble *)(b4 + rr * (N * 8)));
+                 (lds_cdouble *)(b3 + rr * (N * 8)));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (C::F_NBUF == 2 && i + 1 < T) // one stage ahead, behind this stage's arithmetic
         issue_forward(i + 1, lds + (fbuf ^ 1) * C::F_BYTES);
     } else {
       read_stage(pm + (long)i * STG + L::NODE, pg + (long)i * L::GAIN,
-                 pw + (long)(i + 1) * WSN, pv + (long)(i + 1) * VSTG + N,
-                 pm + (long)(i + 1) * STG + N * N);
+                 pw + (long)(i + 1) * WSN, pm + (long)(i + 1) * STG + N * N);
     }
 
+    const double sdi = rsqrt_nr(dd), sdv = dd * sdi; // as node_factor computed them
     double acc[4];
     // u = k + K x  (lqr.cpp:856-857); lanes < M
     acc[0] = kk0, acc[1] = 0.0, acc[2] = 0.0, acc[3] = 0.0;
@@ -751,11 +770,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     dotv<N, true>(acc, x, Arow);
     dotv<M, true>(acc, u, Brow);
     const double z = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    // y_c = g_c + W_c z ; x_c = z + c_c - delta_c o y_c
-    acc[0] = gg, acc[1] = 0.0, acc[2] = 0.0, acc[3] = 0.0;
-    dotv<N, true>(acc, z, Wc);
-    y = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    x = z + (cc - dd * y);
+    // zeta = D^{-1/2} z;  x_c = D^{1/2} (S zeta + h);  y_c = g_c + D^{-1/2} (zeta - S zeta)
+    const double zeta = z * sdi;
+    acc[0] = 0.0, acc[1] = 0.0, acc[2] = 0.0, acc[3] = 0.0;
+    dotv<N, true>(acc, zeta, Wc);
+    const double sz = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    x = sdv * (sz + hh);
+    y = __builtin_fma(sdi, zeta - sz, gg);
     if (valid) {
       double *si = ps + (long)i * VSTG;
 #if SIP_LQR_NT_SOL

@@ -13,6 +13,7 @@ Blocks (all lanes of the wave must be active; a "row" is 16 consecutive lanes):
   rank1<R,K,NEG,WAIT>(C, A, b)   C[i] (+/-)= A[i]@lane K of the row * b, i < R
   spread<R,NEG,WAIT>(C, a, b)    C[i] (+/-)= a@lane i of the row * b,    i < R
   dotv<R,WAIT>(acc, x, B)        acc[k % 4] += x@lane k of the row * B[k], k < R
+  spreadv<R,WAIT>(C, a, B)       C[i] += a@lane i of the row * B[i],     i < R
 
 WAIT prepends `s_nop 1`: the two wait states gfx9 needs between a VALU write of
 a VGPR and a DPP read of it (the compiler pads its own instructions but not
@@ -84,6 +85,23 @@ def emit_dotv(out, R):
     out.append("}\n")
 
 
+def emit_spreadv(out, R):
+    # operands: %0..%R-1 = C (rw), %R = a, %R+1.. = B[i]
+    outs = ", ".join(f'"+v"(C[{i}])' for i in range(R))
+    ins = '"v"(a), ' + ", ".join(f'"v"(B[{i}])' for i in range(R))
+    out.append(f"template <bool WAIT>\n"
+               f"__device__ __forceinline__ void spreadv_{R}(double *C, double a, const double *B) {{")
+    for wait in (False, True):
+        lines = ["s_nop 1"] if wait else []
+        for i in range(R):
+            lines.append(f"v_fmac_f64_dpp %{i}, %{R}, %{R + 1 + i} row_newbcast:{i} "
+                         "row_mask:0xf bank_mask:0xf")
+        s = "\\n\\t".join(lines)
+        out.append(f"  if constexpr (WAIT == {str(wait).lower()})\n"
+                   f'    asm volatile("{s}"\n        : {outs}\n        : {ins});')
+    out.append("}\n")
+
+
 def emit_x(out, kind, R, K):
     """Whole products in one asm statement (fewer statement boundaries for the
     compiler to pad): rank1x: C[i] += A[i]@lane k * B[k]; spreadx: C[i] += A[k]@lane i * B[k]."""
@@ -125,6 +143,7 @@ def main(path):
         emit_rank1(out, R)
         emit_spread(out, R)
         emit_dotv(out, R)
+        emit_spreadv(out, R)
     for R in XSIZES:
         for K in XSIZES:
             emit_x(out, "rank1x", R, K)
@@ -158,6 +177,12 @@ def main(path):
     out.append("  static_assert(R >= 0 && R <= %d);" % MAXR)
     for R in range(1, MAXR + 1):
         out.append(f"  if constexpr (R == {R}) dppgen::dotv_{R}<WAIT>(acc, x, B);")
+    out.append("}\n")
+    out.append("template <int R, bool WAIT>\n"
+               "__device__ __forceinline__ void spreadv(double *C, double a, const double *B) {")
+    out.append("  static_assert(R >= 0 && R <= %d);" % MAXR)
+    for R in range(1, MAXR + 1):
+        out.append(f"  if constexpr (R == {R}) dppgen::spreadv_{R}<WAIT>(C, a, B);")
     out.append("}\n")
     out.append("} // namespace sipamd")
     with open(path, "w") as f:

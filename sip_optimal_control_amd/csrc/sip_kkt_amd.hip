@@ -254,8 +254,9 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
       p->name = std::string("chain:") + sip_lqr_kernel_name(p->chain);
     }
   } else {
-    rc = sip_lqr_tree_plan_create(batch, E, root, p->parents.data(), p->children.data(), p->sd.data(),
-                                  p->cd.data(), device, &p->tree);
+    const int none = 0; // an edge-less tree still needs non-null edge arrays (lqr.cpp:566-569)
+    rc = sip_lqr_tree_plan_create(batch, E, root, E ? p->parents.data() : &none, E ? p->children.data() : &none,
+                                  p->sd.data(), E ? p->cd.data() : &none, device, &p->tree);
     if (rc == SIP_LQR_OK && sip_lqr_tree_topology_status(p->tree) != SIP_LQR_SUCCESS) {
       p->input_status = sip_lqr_tree_topology_status(p->tree); // INVALID_TOPOLOGY, latched
       p->name = "invalid topology";

@@ -66,6 +66,7 @@ def test_reference_cases(name):
     rhs2 = np.cos(np.arange(batch * dims.kkt_dim)).reshape(batch, -1)
     sol3 = kkt.solve(d[0], _dev(rhs2)[0]).cpu().numpy()
     for p in range(batch):
+        assert o.factor(model_b[p], w_b[p], r1_b[p], r2_b[p], r3_b[p]) == 0
         ref = o.solve(model_b[p], rhs2[p])
         assert np.abs(sol3[p] - ref).max() <= REL * max(1.0, np.abs(ref).max())
 

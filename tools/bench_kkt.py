@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Newton-KKT factor+solve throughput on one MI355X: the
+loop body of the reference's BM_NewtonKKTFactorSolve
+(benchmarks/newton_kkt_benchmark.cpp:316-324) over a batch of NewtonKKTProblem
+(n, m, T) instances (c = n/2 equality and g = 2m inequality rows per edge and
+on the last node), device-resident.
+
+    python tools/bench_kkt.py [--n 12 --m 4 --T 50 --batch 4096] [--steps 30]
+
+Prints one JSON line: solves/s, the per-launch split (condense+rhs | Riccati |
+recover), the HBM roofline of the whole step (algorithmic bytes = model +
+w, r1, r2, r3, b read once, sol written once) and the oracle on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=12)
+    ap.add_argument("--m", type=int, default=4)
+    ap.add_argument("--T", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from sip_optimal_control_amd import BatchedNewtonKKT, synthetic
+    n, m, T, batch = args.n, args.m, args.T, args.batch
+    c, g = max(1, n // 2), max(1, 2 * m)
+    dims = dict(parents=list(range(T)), children=list(range(1, T + 1)), state_dims=[n] * (T + 1),
+                control_dims=[m] * T, node_c_dims=[0] * T + [c], node_g_dims=[0] * T + [g],
+                edge_c_dims=[c] * T, edge_g_dims=[g] * T)
+    kkt = BatchedNewtonKKT(batch=batch, **dims)
+    data = synthetic.make_newton_kkt_batch(kkt, seed=0, r2_max=1e2, **dims)
+    sol = torch.zeros(batch, kkt.kkt_dim, dtype=torch.float64, device=kkt.device)
+    for _ in range(args.warmup):
+        kkt.factor_solve(*data, sol=sol)
+    torch.cuda.synchronize()
+    assert int((kkt.status != 0).sum()) == 0, "factorization failed on the synthetic batch"
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(args.steps):
+        kkt.factor_solve(*data, sol=sol)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / args.steps
+    # residual through the GPU operator (the benchmark's residual_norm counter, :110-124)
+    prod = kkt.add_Kx_to_y(*data[:5], sol)
+    res = float((prod - data[5]).norm(dim=1).max())
+    alg_bytes = 8 * (kkt.model_len + 2 * kkt.z_dim + kkt.x_dim + kkt.y_dim + 2 * kkt.kkt_dim)
+    out = {
+        "metric": "newton_kkt_factor_solves_per_sec", "value": batch / (ms * 1e-3), "unit": "solves/s",
+        "ms_per_step": ms, "n_gpus": 1, "steps": args.steps, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"NewtonKKTProblem(n={n}, m={m}, T={T}), c={c}, g={g}, batch {batch}",
+                   "riccati": kkt.kernel_name},
+        "max_residual_norm": res,
+        "roofline": {"bound": "hbm", "achieved": batch * alg_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": batch * alg_bytes / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None},
+        "algorithmic_bytes_per_solve": alg_bytes,
+    }
+    if args.cpu_seconds > 0:
+        from oracle.kkt import KKTDims, KKTOracle
+        sys.path.insert(0, ROOT)
+        from bench import usable_cores
+        od = KKTDims(dims["parents"], dims["children"], dims["state_dims"], dims["control_dims"],
+                     dims["node_c_dims"], dims["node_g_dims"], dims["edge_c_dims"], dims["edge_g_dims"])
+        cores = usable_cores()
+        sample = min(batch, max(128, 8 * cores))
+        host = [a[:sample].cpu().numpy() for a in data]
+        o = KKTOracle(od)
+        o.batch(*[a[:4] for a in host], threads=1)
+        t0 = time.perf_counter()
+        ref, st = o.batch(*host, threads=cores)
+        once = time.perf_counter() - t0
+        reps = max(1, int(args.cpu_seconds / max(once, 1e-6)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o.batch(*host, threads=cores)
+        dt = time.perf_counter() - t0
+        err = float(np.abs(sol[:sample].cpu().numpy() - ref).max() / np.abs(ref).max())
+        out["cpu_baseline"] = {"value": sample * reps / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+                               "sample": f"{sample} problems x {reps} on {cores} threads, oracle/kkt_oracle.c"}
+        out["max_rel_err_vs_oracle"] = err
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
