@@ -39,6 +39,9 @@ struct Meta {
   // 1 where a y row is a dynamics row (weight = r2 itself), else 0
   const int *y_is_dyn;
   const long *mo[NUM_BLOCKS]; // model arena block offsets
+  // LDS plan of the staged kernels (doubles): Q accumulator | one model item |
+  // the weighted copy of its Jacobian tail | weighted right-hand side rows
+  int lds_q, lds_item, lds_tail, lds_rows;
   // offsets inside the LQR arenas (generic_plan.hpp tables)
   const long *oQ, *od, *oq, *oc, *ox, *oy, *oA, *oB, *oM, *oR, *orr, *ou;
 };
@@ -263,6 +266,322 @@ recover_kernel(const Meta mt, const double *__restrict__ model_all, const double
         const int at = mt.z_edge[e] + (k - c);
         const double jx = row_dot(model + mt.mo[E_JXG][e], k - c, g, n, x);
         const double ju = row_dot(model + mt.mo[E_JUG][e], k - c, g, m, u);
+        sol_z[at] = ((jx + ju) - b_z[at]) * zinv[at];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Staged variants: one workgroup per (problem, node).  The model item of the
+// node ([d2L_dx2 | dc_dx | dg_dx], contiguous) and then of each child edge
+// ([d2L_dx2 | d2L_dxdu | d2L_du2 | ddyn_dx | ddyn_du | dc_dx | dc_du | dg_dx |
+// dg_du], contiguous) is copied HBM -> LDS with coalesced loads, the
+// weighted Jacobians w o J are formed once in LDS, and every output element is
+// accumulated from LDS by one lane in the same order and with the same
+// operations as the direct kernels above (bit-identical results).  Q_mod is
+// accumulated in LDS across the child edges; q_mod in a register.
+// ---------------------------------------------------------------------------
+// All the loads of a pass are issued before the first LDS store (a plain copy
+// loop waits for each load in turn: one HBM round trip per 512 bytes).
+__device__ __forceinline__ void stage_copy(double *dst, const double *__restrict__ src, int len, int tid) {
+  constexpr int U = 8;
+  for (int base = tid; base < len; base += U * TPB) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (base + u * TPB < len)
+        v[u] = src[base + u * TPB];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (base + u * TPB < len)
+        dst[base + u * TPB] = v[u];
+  }
+}
+
+// acc += sum_k JW[k, cb] * J[k, ca]   (both column-major with `rows` rows, in LDS)
+__device__ __forceinline__ double rank_update_w(double acc, const double *J, int ca, const double *JW, int cb,
+                                                int rows) {
+  const double *a = J + rows * ca, *b = JW + rows * cb;
+  for (int k = 0; k < rows; ++k)
+    acc += b[k] * a[k];
+  return acc;
+}
+
+// acc -= sum_k J[k, col] * wr[k]
+__device__ __forceinline__ double sub_weighted_w(double acc, const double *J, int col, int rows, const double *wr) {
+  const double *a = J + rows * col;
+  for (int k = 0; k < rows; ++k)
+    acc -= a[k] * wr[k];
+  return acc;
+}
+
+template <bool WITH_RHS>
+__global__ void __launch_bounds__(TPB)
+condense_staged_kernel(const Meta mt, const double *__restrict__ model_all, const double *__restrict__ r1_all,
+                       const double *__restrict__ inv_all, double *__restrict__ in0_all,
+                       const double *__restrict__ b_all, double *__restrict__ in1_all, long batch) {
+  extern __shared__ double sm[];
+  double *Qacc = sm, *buf = Qacc + mt.lds_q, *jw = buf + mt.lds_item, *wr = jw + mt.lds_tail;
+  const long p = blockIdx.x / mt.N;
+  const int i = blockIdx.x - (unsigned)(p * mt.N);
+  if (p >= batch)
+    return;
+  const long kkt = (long)mt.x_dim + mt.y_dim + mt.z_dim;
+  const double *model = model_all + p * mt.model_len;
+  const double *r1 = r1_all + p * mt.x_dim;
+  const double *yinv = inv_all + p * ((long)mt.y_dim + mt.z_dim), *zinv = yinv + mt.y_dim;
+  const double *b = WITH_RHS ? b_all + p * kkt : nullptr;
+  const double *b_y = WITH_RHS ? b + mt.x_dim : nullptr, *b_z = WITH_RHS ? b_y + mt.y_dim : nullptr;
+  double *in0 = in0_all + p * mt.in0_len;
+  double *in1 = WITH_RHS ? in1_all + p * mt.in1_len : nullptr;
+  const int tid = threadIdx.x;
+  const int n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];
+
+  // ---- the node's own terms (helpers.cpp:299-318, 752-779) ----
+  stage_copy(buf, model + mt.mo[N_Q][i], n * n + (c + g) * n, tid);
+  __syncthreads();
+  {
+    const double *Jc = buf + n * n, *Jg = Jc + c * n;
+    const double *wc = yinv + mt.y_node_c[i], *wg = zinv + mt.z_node[i];
+    for (int idx = tid; idx < c * n; idx += TPB)
+      jw[idx] = wc[idx % c] * Jc[idx];
+    for (int idx = tid; idx < g * n; idx += TPB)
+      jw[c * n + idx] = wg[idx % g] * Jg[idx];
+    if (WITH_RHS) {
+      for (int k = tid; k < c + g; k += TPB)
+        wr[k] = k < c ? wc[k] * b_y[mt.y_node_c[i] + k] : wg[k - c] * b_z[mt.z_node[i] + (k - c)];
+    }
+  }
+  __syncthreads();
+  double qacc = 0.0; // lane d < n: q_mod[d] (n <= TPB handled by the loop below otherwise)
+  {
+    const double *Jc = buf + n * n, *Jg = Jc + c * n;
+    for (int idx = tid; idx < n * n; idx += TPB) {
+      const int col = idx / n, row = idx - col * n;
+      if (row < col)
+        continue;
+      double acc = buf[idx];
+      if (row == col)
+        acc += r1[mt.x_state[i] + row];
+      acc = rank_update_w(acc, Jc, row, jw, col, c);
+      acc = rank_update_w(acc, Jg, row, jw + c * n, col, g);
+      Qacc[idx] = acc;
+    }
+    if (WITH_RHS) {
+      for (int d = tid; d < n; d += TPB) {
+        double acc = -b[mt.x_state[i] + d];
+        acc = sub_weighted_w(acc, Jc, d, c, wr);
+        acc = sub_weighted_w(acc, Jg, d, g, wr + c);
+        if (n <= TPB)
+          qacc = acc;
+        else
+          in1[mt.oq[i] + d] = acc;
+        in1[mt.oc[i] + d] = -b_y[mt.y_dyn[i] + d];
+      }
+    }
+    for (int d = tid; d < n; d += TPB)
+      in0[mt.od[i] + d] = yinv[mt.y_dyn[i] + d];
+  }
+
+  // ---- child edges in index order (helpers.cpp:320-355, 781-812) ----
+  for (int ci = mt.child_offsets[i]; ci < mt.child_offsets[i + 1]; ++ci) {
+    const int e = mt.child_edges[ci];
+    const int nc = mt.sd[mt.child[e]], m = mt.cd[e], ce = mt.ecd[e], ge = mt.egd[e];
+    const int o_m = n * n, o_r = o_m + n * m, o_a = o_r + m * m, o_b = o_a + nc * n, o_j = o_b + nc * m;
+    const int tail = (ce + ge) * (n + m);
+    __syncthreads(); // previous consumers of buf / jw / wr are done
+    stage_copy(buf, model + mt.mo[E_Q][e], o_j + tail, tid);
+    __syncthreads();
+    const double *Jxc = buf + o_j, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
+    double *wxc = jw, *wuc = wxc + ce * n, *wxg = wuc + ce * m, *wug = wxg + ge * n;
+    {
+      const double *wc = yinv + mt.y_edge_c[e], *wg = zinv + mt.z_edge[e];
+      for (int idx = tid; idx < ce * (n + m); idx += TPB)
+        wxc[idx] = wc[idx % ce] * Jxc[idx]; // [Jxc | Juc] share the row count
+      for (int idx = tid; idx < ge * (n + m); idx += TPB)
+        wxg[idx] = wg[idx % ge] * Jxg[idx];
+      if (WITH_RHS) {
+        for (int k = tid; k < ce + ge; k += TPB)
+          wr[k] = k < ce ? wc[k] * b_y[mt.y_edge_c[e] + k] : wg[k - ce] * b_z[mt.z_edge[e] + (k - ce)];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += TPB) { // Q_mod[parent] += ..., :336-339
+      const int col = idx / n, row = idx - col * n;
+      if (row < col)
+        continue;
+      double acc = Qacc[idx] + buf[idx];
+      acc = rank_update_w(acc, Jxc, row, wxc, col, ce);
+      acc = rank_update_w(acc, Jxg, row, wxg, col, ge);
+      Qacc[idx] = acc;
+    }
+    double *Mm = in0 + mt.oM[e], *Rm = in0 + mt.oR[e];
+    for (int idx = tid; idx < n * m; idx += TPB) { // M_mod, :341-352
+      const int col = idx / n, row = idx - col * n;
+      double acc = buf[o_m + idx];
+      acc = rank_update_w(acc, Jxc, row, wuc, col, ce);
+      acc = rank_update_w(acc, Jxg, row, wug, col, ge);
+      Mm[idx] = acc;
+    }
+    for (int idx = tid; idx < m * m; idx += TPB) { // R_mod, :344-353
+      const int col = idx / m, row = idx - col * m;
+      if (row < col)
+        continue;
+      double acc = buf[o_r + row + m * col];
+      if (row == col)
+        acc += r1[mt.x_control[e] + row];
+      acc = rank_update_w(acc, Juc, row, wuc, col, ce);
+      acc = rank_update_w(acc, Jug, row, wug, col, ge);
+      Rm[row + (long)m * col] = acc;
+      Rm[col + (long)m * row] = acc;
+    }
+    double *Am = in0 + mt.oA[e], *Bm = in0 + mt.oB[e]; // :365-366
+    for (int idx = tid; idx < nc * n; idx += TPB)
+      Am[idx] = buf[o_a + idx];
+    for (int idx = tid; idx < nc * m; idx += TPB)
+      Bm[idx] = buf[o_b + idx];
+    if (WITH_RHS) {
+      for (int d = tid; d < n; d += TPB) { // q_mod[parent] -= ..., :805-806
+        double acc = n <= TPB ? qacc : in1[mt.oq[i] + d];
+        acc = sub_weighted_w(acc, Jxc, d, ce, wr);
+        acc = sub_weighted_w(acc, Jxg, d, ge, wr + ce);
+        if (n <= TPB)
+          qacc = acc;
+        else
+          in1[mt.oq[i] + d] = acc;
+      }
+      for (int d = tid; d < m; d += TPB) { // r_mod, :807-809
+        double acc = -b[mt.x_control[e] + d];
+        acc = sub_weighted_w(acc, Juc, d, ce, wr);
+        acc = sub_weighted_w(acc, Jug, d, ge, wr + ce);
+        in1[mt.orr[e] + d] = acc;
+      }
+    }
+  }
+  if (WITH_RHS && n <= TPB && tid < n)
+    in1[mt.oq[i] + tid] = qacc;
+  // Q_mod out, mirrored (:357-361); each lane writes the elements it accumulated
+  double *Qm = in0 + mt.oQ[i];
+  for (int idx = tid; idx < n * n; idx += TPB) {
+    const int col = idx / n, row = idx - col * n;
+    if (row < col)
+      continue;
+    const double acc = Qacc[idx];
+    Qm[idx] = acc;
+    Qm[col + (long)n * row] = acc;
+  }
+}
+
+// rhs alone (the split solve path): stages only the Jacobian tails.
+__global__ void __launch_bounds__(TPB)
+rhs_staged_kernel(const Meta mt, const double *__restrict__ model_all, const double *__restrict__ b_all,
+                  const double *__restrict__ inv_all, double *__restrict__ in1_all,
+                  const int32_t *__restrict__ status, long batch) {
+  extern __shared__ double sm[];
+  double *buf = sm, *wr = buf + mt.lds_tail;
+  const long p = blockIdx.x / mt.N;
+  const int i = blockIdx.x - (unsigned)(p * mt.N);
+  if (p >= batch || (status != nullptr && status[p] != 0))
+    return;
+  const long kkt = (long)mt.x_dim + mt.y_dim + mt.z_dim;
+  const double *model = model_all + p * mt.model_len;
+  const double *b = b_all + p * kkt, *b_y = b + mt.x_dim, *b_z = b_y + mt.y_dim;
+  const double *yinv = inv_all + p * ((long)mt.y_dim + mt.z_dim), *zinv = yinv + mt.y_dim;
+  double *in1 = in1_all + p * mt.in1_len;
+  const int tid = threadIdx.x;
+  const int n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];
+  stage_copy(buf, model + mt.mo[N_JC][i], (c + g) * n, tid);
+  for (int k = tid; k < c + g; k += TPB)
+    wr[k] = k < c ? yinv[mt.y_node_c[i] + k] * b_y[mt.y_node_c[i] + k]
+                  : zinv[mt.z_node[i] + (k - c)] * b_z[mt.z_node[i] + (k - c)];
+  __syncthreads();
+  for (int d = tid; d < n; d += TPB) {
+    double acc = -b[mt.x_state[i] + d];
+    acc = sub_weighted_w(acc, buf, d, c, wr);
+    acc = sub_weighted_w(acc, buf + c * n, d, g, wr + c);
+    in1[mt.oq[i] + d] = acc;
+    in1[mt.oc[i] + d] = -b_y[mt.y_dyn[i] + d];
+  }
+  for (int ci = mt.child_offsets[i]; ci < mt.child_offsets[i + 1]; ++ci) {
+    const int e = mt.child_edges[ci], m = mt.cd[e], ce = mt.ecd[e], ge = mt.egd[e];
+    __syncthreads();
+    stage_copy(buf, model + mt.mo[E_JXC][e], (ce + ge) * (n + m), tid);
+    for (int k = tid; k < ce + ge; k += TPB)
+      wr[k] = k < ce ? yinv[mt.y_edge_c[e] + k] * b_y[mt.y_edge_c[e] + k]
+                     : zinv[mt.z_edge[e] + (k - ce)] * b_z[mt.z_edge[e] + (k - ce)];
+    __syncthreads();
+    const double *Jxc = buf, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
+    for (int d = tid; d < n; d += TPB) {
+      double acc = in1[mt.oq[i] + d]; // written by this lane above
+      acc = sub_weighted_w(acc, Jxc, d, ce, wr);
+      acc = sub_weighted_w(acc, Jxg, d, ge, wr + ce);
+      in1[mt.oq[i] + d] = acc;
+    }
+    for (int d = tid; d < m; d += TPB) {
+      double acc = -b[mt.x_control[e] + d];
+      acc = sub_weighted_w(acc, Juc, d, ce, wr);
+      acc = sub_weighted_w(acc, Jug, d, ge, wr + ce);
+      in1[mt.orr[e] + d] = acc;
+    }
+  }
+}
+
+// recover: stages the Jacobian tails and the node's x (and each edge's u).
+__global__ void __launch_bounds__(TPB)
+recover_staged_kernel(const Meta mt, const double *__restrict__ model_all, const double *__restrict__ b_all,
+                      const double *__restrict__ inv_all, const double *__restrict__ out_all,
+                      double *__restrict__ sol_all, const int32_t *__restrict__ status, long batch) {
+  extern __shared__ double sm[];
+  double *buf = sm, *xs = buf + mt.lds_tail, *us = xs + mt.lds_rows; // lds_rows >= max n, max m
+  const long p = blockIdx.x / mt.N;
+  const int i = blockIdx.x - (unsigned)(p * mt.N);
+  if (p >= batch || status[p] != 0)
+    return;
+  const long kkt = (long)mt.x_dim + mt.y_dim + mt.z_dim;
+  const double *model = model_all + p * mt.model_len;
+  const double *b_y = b_all + p * kkt + mt.x_dim, *b_z = b_y + mt.y_dim;
+  const double *yinv = inv_all + p * ((long)mt.y_dim + mt.z_dim), *zinv = yinv + mt.y_dim;
+  const double *out = out_all + p * mt.out_len;
+  double *sol = sol_all + p * kkt, *sol_y = sol + mt.x_dim, *sol_z = sol_y + mt.y_dim;
+  const int tid = threadIdx.x;
+  const int n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];
+  stage_copy(buf, model + mt.mo[N_JC][i], (c + g) * n, tid);
+  for (int d = tid; d < n; d += TPB) {
+    const double xv = out[mt.ox[i] + d];
+    xs[d] = xv;
+    sol[mt.x_state[i] + d] = xv;
+    sol_y[mt.y_dyn[i] + d] = out[mt.oy[i] + d];
+  }
+  __syncthreads();
+  for (int k = tid; k < c + g; k += TPB) {
+    if (k < c) {
+      const int at = mt.y_node_c[i] + k;
+      sol_y[at] = (row_dot(buf, k, c, n, xs) - b_y[at]) * yinv[at];
+    } else {
+      const int at = mt.z_node[i] + (k - c);
+      sol_z[at] = (row_dot(buf + c * n, k - c, g, n, xs) - b_z[at]) * zinv[at];
+    }
+  }
+  for (int ci = mt.child_offsets[i]; ci < mt.child_offsets[i + 1]; ++ci) {
+    const int e = mt.child_edges[ci], m = mt.cd[e], ce = mt.ecd[e], ge = mt.egd[e];
+    __syncthreads();
+    stage_copy(buf, model + mt.mo[E_JXC][e], (ce + ge) * (n + m), tid);
+    for (int d = tid; d < m; d += TPB) {
+      const double uv = out[mt.ou[e] + d];
+      us[d] = uv;
+      sol[mt.x_control[e] + d] = uv;
+    }
+    __syncthreads();
+    const double *Jxc = buf, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
+    for (int k = tid; k < ce + ge; k += TPB) {
+      if (k < ce) {
+        const int at = mt.y_edge_c[e] + k;
+        const double jx = row_dot(Jxc, k, ce, n, xs), ju = row_dot(Juc, k, ce, m, us);
+        sol_y[at] = ((jx + ju) - b_y[at]) * yinv[at];
+      } else {
+        const int at = mt.z_edge[e] + (k - ce);
+        const double jx = row_dot(Jxg, k - ce, ge, n, xs), ju = row_dot(Jug, k - ce, ge, m, us);
         sol_z[at] = ((jx + ju) - b_z[at]) * zinv[at];
       }
     }

@@ -6,11 +6,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "generic_plan.hpp"
+#include "kkt_chain_kernels.hpp"
 #include "kkt_kernels.hpp"
 
 struct sip_kkt_plan {
@@ -31,6 +34,11 @@ struct sip_kkt_plan {
   size_t at_in0 = 0, at_in1 = 0, at_out = 0, at_gain = 0, at_inv = 0, at_reg = 0, at_lqr = 0, work_bytes = 0;
   void *d_ints = nullptr, *d_longs = nullptr;
   sipamd::kkt::Meta meta{};
+  bool chain_kernels = false; // uniform chain: arithmetic-offset kernels (kkt_chain_kernels.hpp)
+  sipamd::kkt::ChainKkt ck{};
+  size_t lds_chain_condense = 0, lds_chain_recover = 0;
+  bool staged = false; // LDS-staged kernels (false: items too large for LDS, or SIP_KKT_VARIANT=direct)
+  size_t lds_condense = 0, lds_rhs = 0, lds_recover = 0;
   std::string name;
 
   ~sip_kkt_plan() {
@@ -108,9 +116,24 @@ Regions regions(const sip_kkt_plan *p, void *work) {
 }
 
 unsigned item_grid(const sip_kkt_plan *p) { return (unsigned)(p->batch * (p->N + p->E)); }
+unsigned node_grid(const sip_kkt_plan *p) { return (unsigned)(p->batch * p->N); }
 
+// Uniform chain whose constraint dimensions are uniform too (interior nodes, terminal node, edges).
+bool uniform_constraints(const sip_kkt_plan &p) {
+  for (int i = 1; i < p.E; ++i)
+    if (p.ncd[i] != p.ncd[0] || p.ngd[i] != p.ngd[0])
+      return false;
+  for (int e = 1; e < p.E; ++e)
+    if (p.ecd[e] != p.ecd[0] || p.egd[e] != p.egd[0])
+      return false;
+  return p.sd[0] <= 32 && p.cd[0] <= 32;
+}
+int even(int v) { return (v + 1) / 2 * 2; }
+
+// b != nullptr (fused factor+solve on the staged kernels): also builds q_mod, r_mod, c_mod.
 hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double *model, const double *w,
-                           const double *r1, const double *r2, const double *r3, hipStream_t s) {
+                           const double *r1, const double *r2, const double *r3, const double *b,
+                           hipStream_t s) {
   hipError_t e = hipMemsetAsync(r.reg, 0, (size_t)p->batch * sizeof(int), s);
   if (e != hipSuccess)
     return e;
@@ -118,8 +141,23 @@ hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double
   if (per > 0)
     hipLaunchKernelGGL(sipamd::kkt::weights_kernel, dim3((unsigned)((p->batch * per + 255) / 256)), dim3(256), 0, s,
                        p->meta, w, r2, r3, r.inv, r.reg, (long)p->batch);
-  hipLaunchKernelGGL(sipamd::kkt::condense_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta, model,
-                     r1, r.inv, r.in0, (long)p->batch);
+  if (p->chain_kernels && b != nullptr)
+    hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
+  else if (p->chain_kernels)
+    hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, (const double *)nullptr,
+                       (double *)nullptr, (long)p->batch);
+  else if (p->staged && b != nullptr) // condensation and right-hand side from one staging of the model
+    hipLaunchKernelGGL(sipamd::kkt::condense_staged_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_condense, s, p->meta, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
+  else if (p->staged)
+    hipLaunchKernelGGL(sipamd::kkt::condense_staged_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_condense, s, p->meta, model, r1, r.inv, r.in0, (const double *)nullptr,
+                       (double *)nullptr, (long)p->batch);
+  else
+    hipLaunchKernelGGL(sipamd::kkt::condense_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta,
+                       model, r1, r.inv, r.in0, (long)p->batch);
   return hipGetLastError();
 }
 
@@ -131,15 +169,26 @@ hipError_t launch_merge(const sip_kkt_plan *p, const Regions &r, int32_t *status
 
 hipError_t launch_rhs(const sip_kkt_plan *p, const Regions &r, const double *model, const double *b,
                       const int32_t *status, hipStream_t s) {
-  hipLaunchKernelGGL(sipamd::kkt::rhs_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta, model, b,
-                     r.inv, r.in1, status, (long)p->batch);
+  if (p->staged)
+    hipLaunchKernelGGL(sipamd::kkt::rhs_staged_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_rhs, s,
+                       p->meta, model, b, r.inv, r.in1, status, (long)p->batch);
+  else
+    hipLaunchKernelGGL(sipamd::kkt::rhs_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta, model,
+                       b, r.inv, r.in1, status, (long)p->batch);
   return hipGetLastError();
 }
 
 hipError_t launch_recover(const sip_kkt_plan *p, const Regions &r, const double *model, const double *b,
                           double *sol, const int32_t *status, hipStream_t s) {
-  hipLaunchKernelGGL(sipamd::kkt::recover_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta, model,
-                     b, r.inv, r.out, sol, status, (long)p->batch);
+  if (p->chain_kernels)
+    hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_recover, s, p->ck, model, b, r.inv, r.out, sol, status, (long)p->batch);
+  else if (p->staged)
+    hipLaunchKernelGGL(sipamd::kkt::recover_staged_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_recover, s, p->meta, model, b, r.inv, r.out, sol, status, (long)p->batch);
+  else
+    hipLaunchKernelGGL(sipamd::kkt::recover_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta,
+                       model, b, r.inv, r.out, sol, status, (long)p->batch);
   return hipGetLastError();
 }
 
@@ -301,6 +350,47 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
       child_edges[cursor[p->parents[e]]++] = e; // stable in the edge index (lqr.cpp:588-598)
   }
 
+  // LDS plan of the staged kernels
+  int lds_q = 0, lds_item = 0, lds_tail = 0, lds_rows = 1;
+  for (int i = 0; i < N; ++i) {
+    const int n = p->sd[i], cg = p->ncd[i] + p->ngd[i];
+    lds_q = std::max(lds_q, n * n), lds_item = std::max(lds_item, n * n + cg * n);
+    lds_tail = std::max(lds_tail, cg * n), lds_rows = std::max(lds_rows, std::max(cg, n));
+  }
+  for (int e = 0; e < E; ++e) {
+    const int n = p->sd[p->parents[e]], nc = p->sd[p->children[e]], m = p->cd[e], cg = p->ecd[e] + p->egd[e];
+    lds_item = std::max(lds_item, n * n + n * m + m * m + nc * n + nc * m + cg * (n + m));
+    lds_tail = std::max(lds_tail, cg * (n + m)), lds_rows = std::max(lds_rows, std::max(cg, m));
+  }
+  p->lds_condense = sizeof(double) * ((size_t)lds_q + lds_item + lds_tail + lds_rows);
+  p->lds_rhs = sizeof(double) * ((size_t)lds_tail + lds_rows);
+  p->lds_recover = sizeof(double) * ((size_t)lds_tail + 2 * (size_t)lds_rows);
+  const char *variant = std::getenv("SIP_KKT_VARIANT");
+  p->staged = p->lds_condense <= 48 * 1024 && !(variant && std::strcmp(variant, "direct") == 0);
+  if (p->chain != nullptr && p->staged && uniform_constraints(*p)) {
+    sipamd::kkt::ChainKkt &ck = p->ck;
+    ck.n = p->sd[0], ck.m = p->cd[0], ck.T = E;
+    ck.cn = E > 1 ? p->ncd[0] : 0, ck.gn = E > 1 ? p->ngd[0] : 0;
+    if (E == 1) // one interior node only: its dimensions are the "interior" ones
+      ck.cn = p->ncd[0], ck.gn = p->ngd[0];
+    ck.cT = p->ncd[E], ck.gT = p->ngd[E], ck.ce = p->ecd[0], ck.ge = p->egd[0];
+    const int n = ck.n, mm = ck.m;
+    ck.node_len = n * n + (ck.cn + ck.gn) * n;
+    ck.edge_len = 2 * n * n + 2 * n * mm + mm * mm + (ck.ce + ck.ge) * (n + mm);
+    ck.model_len = p->model_len, ck.x_dim = p->x_dim, ck.y_dim = p->y_dim, ck.z_dim = p->z_dim;
+    ck.mats_stage = (n * n + n) + (n * n + 2 * n * mm + mm * mm), ck.vecs_stage = 2 * n + mm;
+    ck.mats_len = p->in0_len, ck.vecs_len = p->in1_len;
+    const int cgn = std::max(ck.cn + ck.gn, ck.cT + ck.gT), cge = ck.ce + ck.ge;
+    ck.lds_item = even(n * n + cgn * n + ck.edge_len);
+    ck.lds_tail = even(cgn * n + cge * (n + mm)); // recover: every Jacobian of a stage
+    ck.lds_rows = even(cgn + cge);                // condense: weights | weighted rhs rows
+    p->lds_chain_condense = sizeof(double) * ((size_t)ck.lds_item + 2 * (size_t)ck.lds_rows);
+    p->lds_chain_recover = sizeof(double) * ((size_t)ck.lds_tail + n + mm);
+    p->chain_kernels = p->lds_chain_condense <= 48 * 1024 &&
+                       !(variant && std::strcmp(variant, "tables") == 0);
+  }
+  p->name += p->chain_kernels ? " + chain condensation" : p->staged ? " + staged condensation" : " + direct condensation";
+
   std::vector<int> ints;
   auto pi = [&](const std::vector<int> &v) {
     const size_t where = ints.size();
@@ -347,6 +437,7 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
   Meta &m = p->meta;
   m.E = E, m.N = N, m.root = root, m.x_dim = p->x_dim, m.y_dim = p->y_dim, m.z_dim = p->z_dim;
   m.model_len = p->model_len, m.in0_len = p->in0_len, m.in1_len = p->in1_len, m.out_len = p->out_len;
+  m.lds_q = lds_q, m.lds_item = lds_item, m.lds_tail = lds_tail, m.lds_rows = lds_rows;
   m.sd = di + a_sd, m.cd = di + a_cd, m.ncd = di + a_ncd, m.ngd = di + a_ngd, m.ecd = di + a_ecd, m.egd = di + a_egd;
   m.parent = di + a_pa, m.child = di + a_ch, m.in_edge = di + a_in;
   m.child_offsets = di + a_co, m.child_edges = di + a_ce, m.y_is_dyn = di + a_dyn;
@@ -410,7 +501,7 @@ int sip_kkt_factor(const sip_kkt_plan *p, const double *d_model, const double *d
       (!d_r2 && p->y_dim > 0) || (!d_r3 && p->z_dim > 0) || !d_work)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   const Regions r = regions(p, d_work);
-  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, s);
+  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, nullptr, s);
   if (e != hipSuccess)
     return report(e, "sip_kkt_factor(condense)");
   const int rc = p->chain ? sip_lqr_factor(p->chain, r.in0, r.gain, d_status, r.lqr, s)
@@ -456,8 +547,9 @@ int sip_kkt_factor_solve(const sip_kkt_plan *p, const double *d_model, const dou
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
   const Regions r = regions(p, d_work);
-  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, s);
-  if (e == hipSuccess)
+  const bool fused_rhs = p->staged || p->chain_kernels;
+  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, fused_rhs ? d_b : nullptr, s);
+  if (e == hipSuccess && !fused_rhs)
     e = launch_rhs(p, r, d_model, d_b, nullptr, s);
   if (e != hipSuccess)
     return report(e, "sip_kkt_factor_solve(condense)");

@@ -42,7 +42,7 @@ def test_reference_cases(name):
     model_b, w_b, r1_b, r2_b, r3_b, rhs_b = _batchify(batch, model, w, r1, r2, r3, rhs)
     kkt = _make(dims, batch)
     assert (kkt.x_dim, kkt.y_dim, kkt.z_dim, kkt.model_len) == (dims.x_dim, dims.y_dim, dims.z_dim, dims.model_len)
-    assert kkt.kernel_name == "tree:general"
+    assert kkt.kernel_name == "tree:general + staged condensation"
     d = _dev(model_b, w_b, r1_b, r2_b, r3_b, rhs_b)
     status = kkt.factor(*d[:5])
     assert status.cpu().tolist() == [0] * batch
@@ -187,3 +187,51 @@ def test_null_constraint_dims_and_single_node():
     K = dense_kkt_matrix(one, model1, w1, r11, r21, r31)
     assert st1.cpu().tolist() == [0]
     np.testing.assert_allclose(sol1.cpu().numpy()[0], np.linalg.solve(K, rhs1), rtol=1e-9, atol=1e-11)
+
+
+def test_condensation_variants_agree_bitwise(monkeypatch):
+    """The table-driven LDS-staged kernels and the direct kernels (fallback for items too large for
+    LDS) accumulate every element in the same order with the same operations; the uniform-chain
+    kernels (matrix-pipe rank updates) agree with them to rounding."""
+    dims = rk.newton_kkt_dims(6, 2, 9)
+    batch = 5
+    arrays = rk.newton_kkt_problem(dims, seed=21, batch=batch, r2_max=1e2)
+    d = _dev(*arrays)
+    sols = {}
+    for variant in ("", "tables", "direct"):
+        monkeypatch.setenv("SIP_KKT_VARIANT", variant)
+        kkt = _make(dims, batch)
+        assert kkt.kernel_name.endswith({"": "chain condensation", "tables": "staged condensation",
+                                         "direct": "direct condensation"}[variant])
+        sol, st = kkt.factor_solve(*d)
+        assert st.cpu().tolist() == [0] * batch
+        kkt.factor(*d[:5])
+        sols[variant] = (sol.clone(), kkt.solve(d[0], d[5]).clone())
+    assert torch.equal(sols["tables"][0], sols["direct"][0]) and torch.equal(sols["tables"][1], sols["direct"][1])
+    for pair in (sols[""], sols["tables"]):
+        assert torch.equal(pair[0], pair[1])  # fused and split entry points
+    # the chain kernels sum the rank updates on the matrix pipe: same to rounding
+    scale = sols["tables"][0].abs().amax(dim=1, keepdim=True)
+    assert float(((sols[""][0] - sols["tables"][0]).abs() / scale).max()) <= 1e-12
+    # interior-node constraints too, odd dimensions (scalar LDS paths of the chain kernels)
+    T = 5
+    odd = rk.KKTDims(list(range(T)), list(range(1, T + 1)), [5] * (T + 1), [3] * T, node_c=[1] * T + [2],
+                     node_g=[3] * T + [0], edge_c=[3] * T, edge_g=[1] * T)
+    arrays = rk.newton_kkt_problem(odd, seed=4, batch=3, r2_max=1e2)
+    d = _dev(*arrays)
+    ref, ref_status = KKTOracle(odd).batch(*arrays)
+    got = {}
+    for variant in ("", "direct"):
+        monkeypatch.setenv("SIP_KKT_VARIANT", variant)
+        kkt = _make(odd, 3)
+        got[variant], st = kkt.factor_solve(*d)
+        assert st.cpu().tolist() == ref_status.tolist() == [0, 0, 0]
+    assert float(((got[""] - got["direct"]).abs() / got["direct"].abs().amax(dim=1, keepdim=True)).max()) <= 1e-12
+    assert (np.abs(got[""].cpu().numpy() - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= REL
+    # a branching tree with variable dimensions through the table-driven variants
+    tdims, model, (w, r1, r2, r3, rhs) = rk.reference_case("branch_sibling_edges")
+    td = _dev(model[None], w[None], r1[None], r2[None], r3[None], rhs[None])
+    sol_d, _ = _make(tdims, 1).factor_solve(*td)
+    monkeypatch.delenv("SIP_KKT_VARIANT")
+    sol_s, _ = _make(tdims, 1).factor_solve(*td)
+    assert torch.equal(sol_d, sol_s)
