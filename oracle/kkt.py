@@ -17,11 +17,13 @@ import numpy as np
 
 from . import oracle as _oracle
 
+THETA_NODE_BLOCKS = ("d2L_dxdtheta", "dc_dtheta", "dg_dtheta", "d2L_dtheta2")
+THETA_EDGE_BLOCKS = ("d2L_dxdtheta", "d2L_dudtheta", "ddyn_dtheta", "dc_dtheta", "dg_dtheta", "d2L_dtheta2")
 NODE_BLOCKS = ("d2L_dx2", "dc_dx", "dg_dx")
 EDGE_BLOCKS = ("d2L_dx2", "d2L_dxdu", "d2L_du2", "ddyn_dx", "ddyn_du", "dc_dx", "dc_du", "dg_dx", "dg_du")
 _TABLES = ("x_state", "x_control", "y_dyn", "y_node_c", "y_edge_c", "z_node", "z_edge")
 STATUS_NAMES = dict(_oracle.STATUS_NAMES)
-STATUS_NAMES.update({5: "NONPOSITIVE_REGULARIZATION", 6: "INVALID_INPUT"})
+STATUS_NAMES.update({5: "NONPOSITIVE_REGULARIZATION", 6: "INVALID_INPUT", 7: "THETA_SCHUR_FAILURE"})
 
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int)
@@ -49,6 +51,17 @@ def _lib():
         L.kkt_oracle_add_Kx_to_y.restype = None
         L.kkt_oracle_lqr_block.argtypes = [ctypes.c_void_p, ctypes.c_char, ctypes.c_int]
         L.kkt_oracle_lqr_block.restype = _D
+        L.kkt_oracle_set_theta.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.kkt_oracle_set_theta.restype = None
+        L.kkt_oracle_theta_len.argtypes = [ctypes.c_void_p]
+        L.kkt_oracle_theta_len.restype = ctypes.c_long
+        L.kkt_oracle_theta_offset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.kkt_oracle_theta_offset.restype = ctypes.c_long
+        L.kkt_oracle_factor_theta.argtypes = [ctypes.c_void_p] * 7
+        L.kkt_oracle_solve_theta.argtypes = [ctypes.c_void_p] * 5
+        L.kkt_oracle_solve_theta.restype = None
+        L.kkt_oracle_add_Kx_to_y_theta.argtypes = [ctypes.c_void_p] * 9
+        L.kkt_oracle_add_Kx_to_y_theta.restype = None
         L.kkt_oracle_batch.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_void_p] * 8 + [ctypes.c_int]
         _ready = True
     return L
@@ -70,7 +83,8 @@ class KKTDims:
     (types.cpp:24-64) so tests can cross-check the C and HIP tables."""
 
     def __init__(self, parents, children, state_dims, control_dims, node_c=None, node_g=None,
-                 edge_c=None, edge_g=None, root=0):
+                 edge_c=None, edge_g=None, root=0, theta_dim=0):
+        self.p = int(theta_dim)
         self.parents, self.children = list(parents), list(children)
         self.sd, self.cd = list(state_dims), list(control_dims)
         self.E, self.N, self.root = len(self.cd), len(self.cd) + 1, root
@@ -119,6 +133,50 @@ class KKTDims:
                     self.edge_off[b][i] = at
                     at += sz[0] * sz[1]
         self.model_len = at
+        # theta arena: node i then edge i (kkt_oracle.h)
+        self.theta_node_off = {b: [0] * N for b in THETA_NODE_BLOCKS}
+        self.theta_edge_off = {b: [0] * E for b in THETA_EDGE_BLOCKS}
+        at = 0
+        if self.p > 0:
+            for i in range(N):
+                for b, sz in zip(THETA_NODE_BLOCKS, self.theta_node_shapes(i)):
+                    self.theta_node_off[b][i] = at
+                    at += sz[0] * sz[1]
+                if i < E:
+                    for b, sz in zip(THETA_EDGE_BLOCKS, self.theta_edge_shapes(i)):
+                        self.theta_edge_off[b][i] = at
+                        at += sz[0] * sz[1]
+        self.theta_len = at
+        self.full_dim = self.kkt_dim + self.p  # [x | theta | y | z]
+
+    def theta_node_shapes(self, i):
+        p = self.p
+        return [(self.sd[i], p), (self.ncd[i], p), (self.ngd[i], p), (p, p)]
+
+    def theta_edge_shapes(self, e):
+        p = self.p
+        return [(self.sd[self.parents[e]], p), (self.cd[e], p), (self.sd[self.children[e]], p), (self.ecd[e], p),
+                (self.egd[e], p), (p, p)]
+
+    def pack_theta(self, nodes, edges):
+        out = np.zeros(self.theta_len)
+        for i in range(self.N):
+            for b, shp in zip(THETA_NODE_BLOCKS, self.theta_node_shapes(i)):
+                a = np.asarray(nodes[i][b], dtype=np.float64).reshape(shp)
+                out[self.theta_node_off[b][i]:self.theta_node_off[b][i] + a.size] = a.reshape(-1, order="F")
+        for e in range(self.E):
+            for b, shp in zip(THETA_EDGE_BLOCKS, self.theta_edge_shapes(e)):
+                a = np.asarray(edges[e][b], dtype=np.float64).reshape(shp)
+                out[self.theta_edge_off[b][e]:self.theta_edge_off[b][e] + a.size] = a.reshape(-1, order="F")
+        return out
+
+    def unpack_theta(self, arena):
+        arena = np.asarray(arena, dtype=np.float64)
+        nodes = [{b: arena[self.theta_node_off[b][i]:self.theta_node_off[b][i] + s[0] * s[1]].reshape(s, order="F")
+                  for b, s in zip(THETA_NODE_BLOCKS, self.theta_node_shapes(i))} for i in range(self.N)]
+        edges = [{b: arena[self.theta_edge_off[b][e]:self.theta_edge_off[b][e] + s[0] * s[1]].reshape(s, order="F")
+                  for b, s in zip(THETA_EDGE_BLOCKS, self.theta_edge_shapes(e))} for e in range(self.E)]
+        return nodes, edges
 
     def node_shapes(self, i):
         n = self.sd[i]
@@ -154,7 +212,7 @@ class KKTDims:
         return nodes, edges
 
 
-def dense_kkt_matrix(dims, model, w, r1, r2, r3):
+def dense_kkt_matrix(dims, model, w, r1, r2, r3, theta_model=None):
     """Full regularized KKT matrix from the model blocks (independent of the C code)."""
     nodes, edges = dims.unpack_model(model)
     xd, yd, zd = dims.x_dim, dims.y_dim, dims.z_dim
@@ -189,7 +247,35 @@ def dense_kkt_matrix(dims, model, w, r1, r2, r3):
         zg = sl(o["z_edge"][e], dims.egd[e])
         G[zg, xp] += ed["dg_dx"]
         G[zg, xu] += ed["dg_du"]
-    K = np.zeros((dims.kkt_dim, dims.kkt_dim))
+    if theta_model is not None and dims.p > 0:
+        # x = [stagewise x | theta]: widen H, C, G by the theta columns (helpers.cpp:190-240)
+        p = dims.p
+        tn, te = dims.unpack_theta(theta_model)
+        Hf = np.zeros((xd + p, xd + p))
+        Hf[:xd, :xd] = H
+        Cf = np.hstack([C, np.zeros((yd, p))])
+        Gf = np.hstack([G, np.zeros((zd, p))])
+        th = slice(xd, xd + p)
+        for i in range(dims.N):
+            xs = sl(o["x_state"][i], dims.sd[i])
+            Hf[xs, th] += tn[i]["d2L_dxdtheta"]
+            Hf[th, xs] += tn[i]["d2L_dxdtheta"].T
+            Hf[th, th] += tn[i]["d2L_dtheta2"]
+            Cf[sl(o["y_node_c"][i], dims.ncd[i]), th] += tn[i]["dc_dtheta"]
+            Gf[sl(o["z_node"][i], dims.ngd[i]), th] += tn[i]["dg_dtheta"]
+        for e in range(dims.E):
+            pa, ch = dims.parents[e], dims.children[e]
+            xp, xu = sl(o["x_state"][pa], dims.sd[pa]), sl(o["x_control"][e], dims.cd[e])
+            Hf[xp, th] += te[e]["d2L_dxdtheta"]
+            Hf[th, xp] += te[e]["d2L_dxdtheta"].T
+            Hf[xu, th] += te[e]["d2L_dudtheta"]
+            Hf[th, xu] += te[e]["d2L_dudtheta"].T
+            Hf[th, th] += te[e]["d2L_dtheta2"]
+            Cf[sl(o["y_dyn"][ch], dims.sd[ch]), th] += te[e]["ddyn_dtheta"]
+            Cf[sl(o["y_edge_c"][e], dims.ecd[e]), th] += te[e]["dc_dtheta"]
+            Gf[sl(o["z_edge"][e], dims.egd[e]), th] += te[e]["dg_dtheta"]
+        H, C, G, xd = Hf, Cf, Gf, xd + p
+    K = np.zeros((xd + yd + zd, xd + yd + zd))
     K[:xd, :xd] = H + np.diag(r1)
     K[:xd, xd:xd + yd] = C.T
     K[:xd, xd + yd:] = G.T
@@ -208,6 +294,28 @@ class KKTOracle:
         args += [None] * 4 if null_dims else [_ints(dims.ncd), _ints(dims.ngd), _ints(dims.ecd), _ints(dims.egd)]
         self._keep = args
         self.h = L.kkt_oracle_create(dims.E, dims.root, *args)
+        if dims.p > 0:
+            L.kkt_oracle_set_theta(self.h, dims.p)
+            assert L.kkt_oracle_theta_len(self.h) == dims.theta_len
+
+    def theta_offset(self, block, index):
+        return _lib().kkt_oracle_theta_offset(self.h, block, index)
+
+    def factor_theta(self, model, theta_model, w, r1, r2, r3):
+        keep = [_f64(a) for a in (model, theta_model, w, r1, r2, r3)]
+        return _lib().kkt_oracle_factor_theta(self.h, *[k[1] for k in keep])
+
+    def solve_theta(self, model, theta_model, b):
+        keep = [_f64(a) for a in (model, theta_model, b)]
+        sol = np.zeros(self.dims.full_dim)
+        _lib().kkt_oracle_solve_theta(self.h, *[k[1] for k in keep], sol.ctypes.data)
+        return sol
+
+    def add_Kx_to_y_theta(self, model, theta_model, w, r1, r2, r3, x):
+        keep = [_f64(a) for a in (model, theta_model, w, r1, r2, r3, x)]
+        out = np.zeros(self.dims.full_dim)
+        _lib().kkt_oracle_add_Kx_to_y_theta(self.h, *[k[1] for k in keep], out.ctypes.data)
+        return out
 
     def dim(self, which):
         return _lib().kkt_oracle_dim(self.h, which)

@@ -7,6 +7,7 @@
  */
 #include "kkt_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -31,6 +32,11 @@ struct kkt_oracle {
   double **x, **u, **y;
   lqr_oracle_problem prob;
   lqr_oracle_workspace ws;
+  /* theta (helpers.cpp:190-240, 372-407, 896-951) */
+  int p;
+  long *toff[KKT_TH_NUM_BLOCKS];
+  long theta_len;
+  double *J_theta, *K_inv_J_theta, *S_factor, *theta_rhs, *stagewise_rhs, *stagewise_sol;
 };
 
 static int *dup_ints(const int *src, int count) {
@@ -192,6 +198,10 @@ kkt_oracle *kkt_oracle_create(int num_edges, int root, const int *edge_parents,
 void kkt_oracle_destroy(kkt_oracle *o) {
   if (o == NULL)
     return;
+  for (int b = 0; b < KKT_TH_NUM_BLOCKS; ++b)
+    free(o->toff[b]);
+  free(o->J_theta), free(o->K_inv_J_theta), free(o->S_factor), free(o->theta_rhs);
+  free(o->stagewise_rhs), free(o->stagewise_sol);
   const int E = o->E < 0 ? 0 : o->E, N = o->N;
   if (o->input_valid) {
     lqr_oracle_workspace_free(&o->ws);
@@ -629,4 +639,231 @@ int kkt_oracle_batch(const kkt_oracle *o, long batch, const double *model,
   }
   (void)threads;
   return 0;
+}
+
+
+/* ------------------------------------------------------------------------
+ * theta_dim > 0
+ * ------------------------------------------------------------------------ */
+void kkt_oracle_set_theta(kkt_oracle *o, int theta_dim) {
+  if (!o->input_valid || theta_dim <= 0)
+    return;
+  const int E = o->E, N = o->N, p = theta_dim;
+  o->p = p;
+  for (int b = 0; b < KKT_TH_NUM_BLOCKS; ++b)
+    o->toff[b] = (long *)calloc((size_t)N, sizeof(long));
+  long at = 0;
+  for (int i = 0; i < N; ++i) {
+    o->toff[KKT_TH_NODE_DXDTH][i] = at, at += (long)o->sd[i] * p;
+    o->toff[KKT_TH_NODE_DC][i] = at, at += (long)o->ncd[i] * p;
+    o->toff[KKT_TH_NODE_DG][i] = at, at += (long)o->ngd[i] * p;
+    o->toff[KKT_TH_NODE_DTH2][i] = at, at += (long)p * p;
+    if (i < E) {
+      const int e = i;
+      o->toff[KKT_TH_EDGE_DXDTH][e] = at, at += (long)o->sd[o->parents[e]] * p;
+      o->toff[KKT_TH_EDGE_DUDTH][e] = at, at += (long)o->cd[e] * p;
+      o->toff[KKT_TH_EDGE_DDYN][e] = at, at += (long)o->sd[o->children[e]] * p;
+      o->toff[KKT_TH_EDGE_DC][e] = at, at += (long)o->ecd[e] * p;
+      o->toff[KKT_TH_EDGE_DG][e] = at, at += (long)o->egd[e] * p;
+      o->toff[KKT_TH_EDGE_DTH2][e] = at, at += (long)p * p;
+    }
+  }
+  o->theta_len = at;
+  const long skkt = (long)o->x_dim + o->y_dim + o->z_dim;
+  o->J_theta = (double *)calloc((size_t)(skkt * p + 1), sizeof(double));
+  o->K_inv_J_theta = (double *)calloc((size_t)(skkt * p + 1), sizeof(double));
+  o->S_factor = (double *)calloc((size_t)p * p, sizeof(double));
+  o->theta_rhs = (double *)calloc((size_t)p, sizeof(double));
+  o->stagewise_rhs = (double *)calloc((size_t)skkt + 1, sizeof(double));
+  o->stagewise_sol = (double *)calloc((size_t)skkt + 1, sizeof(double));
+}
+
+long kkt_oracle_theta_len(const kkt_oracle *o) { return o->theta_len; }
+
+long kkt_oracle_theta_offset(const kkt_oracle *o, int block, int index) {
+  if (o->p <= 0 || block < 0 || block >= KKT_TH_NUM_BLOCKS || index < 0 ||
+      index >= (block <= KKT_TH_NODE_DTH2 ? o->N : o->E))
+    return -1;
+  return o->toff[block][index];
+}
+
+#define TBLK(o, tm, block, index) ((tm) + (o)->toff[block][index])
+
+/* dst (rows x p block at row offset `at` of the skkt x p matrix J) (+)= src (rows x p) */
+static void put_rows(double *J, long skkt, int at, const double *src, int rows, int p, int accumulate) {
+  for (int col = 0; col < p; ++col)
+    for (int r = 0; r < rows; ++r) {
+      double *dst = &J[at + r + skkt * col];
+      *dst = (accumulate ? *dst : 0.0) + src[r + (long)rows * col];
+    }
+}
+
+/* form_theta_jacobian, helpers.cpp:190-240 */
+static void form_theta_jacobian(kkt_oracle *o, const double *tm) {
+  const int E = o->E, N = o->N, p = o->p, sx = o->x_dim, yd = o->y_dim;
+  const long skkt = (long)sx + yd + o->z_dim;
+  memset(o->J_theta, 0, sizeof(double) * (size_t)(skkt * p));
+  for (int i = 0; i < N; ++i) {
+    put_rows(o->J_theta, skkt, o->voff[KKT_X_STATE][i], TBLK(o, tm, KKT_TH_NODE_DXDTH, i), o->sd[i], p, 0);
+    put_rows(o->J_theta, skkt, sx + o->voff[KKT_Y_NODE_C][i], TBLK(o, tm, KKT_TH_NODE_DC, i), o->ncd[i], p, 0);
+    put_rows(o->J_theta, skkt, sx + yd + o->voff[KKT_Z_NODE][i], TBLK(o, tm, KKT_TH_NODE_DG, i), o->ngd[i], p, 0);
+  }
+  for (int e = 0; e < E; ++e) {
+    const int parent = o->ws.edge_parents[e], child = o->ws.edge_children[e];
+    put_rows(o->J_theta, skkt, o->voff[KKT_X_STATE][parent], TBLK(o, tm, KKT_TH_EDGE_DXDTH, e), o->sd[parent], p, 1);
+    put_rows(o->J_theta, skkt, o->voff[KKT_X_CONTROL][e], TBLK(o, tm, KKT_TH_EDGE_DUDTH, e), o->cd[e], p, 0);
+    put_rows(o->J_theta, skkt, sx + o->voff[KKT_Y_DYN][child], TBLK(o, tm, KKT_TH_EDGE_DDYN, e), o->sd[child], p, 0);
+    put_rows(o->J_theta, skkt, sx + o->voff[KKT_Y_EDGE_C][e], TBLK(o, tm, KKT_TH_EDGE_DC, e), o->ecd[e], p, 0);
+    put_rows(o->J_theta, skkt, sx + yd + o->voff[KKT_Z_EDGE][e], TBLK(o, tm, KKT_TH_EDGE_DG, e), o->egd[e], p, 0);
+  }
+}
+
+/* CallbackProvider::factor with theta_dim > 0, helpers.cpp:242-407 */
+int kkt_oracle_factor_theta(kkt_oracle *o, const double *model, const double *tm, const double *w,
+                            const double *r1, const double *r2, const double *r3) {
+  const int status = kkt_oracle_factor(o, model, w, r1, r2, r3);
+  if (status != KKT_ORACLE_SUCCESS || o->p <= 0)
+    return status;
+  const int p = o->p, sx = o->x_dim;
+  const long skkt = (long)sx + o->y_dim + o->z_dim;
+  form_theta_jacobian(o, tm); /* :376 */
+  for (int col = 0; col < p; ++col) /* solve_stagewise_kkt_matrix(J_theta, K_inv_J_theta, p), :387 */
+    kkt_oracle_solve(o, model, o->J_theta + skkt * col, o->K_inv_J_theta + skkt * col);
+  double *S = o->S_factor; /* :389-402 */
+  memset(S, 0, sizeof(double) * (size_t)p * p);
+  for (int i = 0; i < o->N; ++i)
+    for (int k = 0; k < p * p; ++k)
+      S[k] += TBLK(o, tm, KKT_TH_NODE_DTH2, i)[k];
+  for (int e = 0; e < o->E; ++e)
+    for (int k = 0; k < p * p; ++k)
+      S[k] += TBLK(o, tm, KKT_TH_EDGE_DTH2, e)[k];
+  for (int d = 0; d < p; ++d)
+    S[d + (long)p * d] += r1[sx + d];
+  for (int col = 0; col < p; ++col)
+    for (int row = 0; row < p; ++row) {
+      double acc = 0.0;
+      for (long r = 0; r < skkt; ++r)
+        acc += o->J_theta[r + skkt * row] * o->K_inv_J_theta[r + skkt * col];
+      S[row + (long)p * col] -= acc;
+    }
+  /* Eigen::LLT in place, lower (:403-406): pivot <= 0 -> NumericalIssue */
+  for (int k = 0; k < p; ++k) {
+    double d = S[k + (long)p * k];
+    for (int j = 0; j < k; ++j)
+      d -= S[k + (long)p * j] * S[k + (long)p * j];
+    if (!(d > 0.0))
+      return KKT_ORACLE_THETA_SCHUR_FAILURE;
+    d = sqrt(d);
+    S[k + (long)p * k] = d;
+    for (int i = k + 1; i < p; ++i) {
+      double v = S[i + (long)p * k];
+      for (int j = 0; j < k; ++j)
+        v -= S[i + (long)p * j] * S[k + (long)p * j];
+      S[i + (long)p * k] = v / d;
+    }
+  }
+  return KKT_ORACLE_SUCCESS;
+}
+
+/* CallbackProvider::solve with theta_dim > 0, helpers.cpp:896-951 */
+void kkt_oracle_solve_theta(kkt_oracle *o, const double *model, const double *tm, const double *b,
+                            double *sol) {
+  (void)tm;
+  if (o->p <= 0) {
+    kkt_oracle_solve(o, model, b, sol);
+    return;
+  }
+  const int p = o->p, sx = o->x_dim, yd = o->y_dim, zd = o->z_dim;
+  const long skkt = (long)sx + yd + zd;
+  const double *b_theta = b + sx, *b_y = b + sx + p, *b_z = b_y + yd;
+  memcpy(o->stagewise_rhs, b, sizeof(double) * (size_t)sx); /* :911-916 */
+  memcpy(o->stagewise_rhs + sx, b_y, sizeof(double) * (size_t)yd);
+  memcpy(o->stagewise_rhs + sx + yd, b_z, sizeof(double) * (size_t)zd);
+  kkt_oracle_solve(o, model, o->stagewise_rhs, o->stagewise_sol); /* :918 */
+  for (int a = 0; a < p; ++a) { /* theta_rhs = b_theta - J_theta^T K^-1 b, :920-926 */
+    double acc = 0.0;
+    for (long r = 0; r < skkt; ++r)
+      acc += o->J_theta[r + skkt * a] * o->stagewise_sol[r];
+    o->theta_rhs[a] = b_theta[a] - acc;
+  }
+  const double *L = o->S_factor; /* two triangular solves, :928-934 */
+  for (int i = 0; i < p; ++i) {
+    double v = o->theta_rhs[i];
+    for (int j = 0; j < i; ++j)
+      v -= L[i + (long)p * j] * o->theta_rhs[j];
+    o->theta_rhs[i] = v / L[i + (long)p * i];
+  }
+  for (int i = p - 1; i >= 0; --i) {
+    double v = o->theta_rhs[i];
+    for (int j = i + 1; j < p; ++j)
+      v -= L[j + (long)p * i] * o->theta_rhs[j];
+    o->theta_rhs[i] = v / L[i + (long)p * i];
+  }
+  for (long r = 0; r < skkt; ++r) { /* stagewise_solution -= K^-1 J_theta theta, :936-939 */
+    double acc = 0.0;
+    for (int a = 0; a < p; ++a)
+      acc += o->K_inv_J_theta[r + skkt * a] * o->theta_rhs[a];
+    o->stagewise_sol[r] -= acc;
+  }
+  memcpy(sol, o->stagewise_sol, sizeof(double) * (size_t)sx); /* :941-950 */
+  memcpy(sol + sx, o->theta_rhs, sizeof(double) * (size_t)p);
+  memcpy(sol + sx + p, o->stagewise_sol + sx, sizeof(double) * (size_t)(yd + zd));
+}
+
+/* theta terms of add_Hx/Cx/CTx/Gx/GTx_to_y (helpers.cpp:1023-1066, 1128-1158,
+ * 1221-1249, 1285-1308, 1344-1367) on top of the stagewise operator */
+void kkt_oracle_add_Kx_to_y_theta(const kkt_oracle *o, const double *model, const double *tm,
+                                  const double *w, const double *r1, const double *r2, const double *r3,
+                                  const double *xv, double *yv) {
+  if (o->p <= 0) {
+    kkt_oracle_add_Kx_to_y(o, model, w, r1, r2, r3, xv, yv);
+    return;
+  }
+  const int E = o->E, N = o->N, p = o->p, sx = o->x_dim, yd = o->y_dim, zd = o->z_dim;
+  const long skkt = (long)sx + yd + zd;
+  /* stagewise part on compacted copies ([x | y | z] without theta) */
+  double *xs = (double *)calloc((size_t)skkt + 1, sizeof(double));
+  double *ys = (double *)calloc((size_t)skkt + 1, sizeof(double));
+  double *r1s = (double *)calloc((size_t)sx + 1, sizeof(double));
+  memcpy(xs, xv, sizeof(double) * (size_t)sx);
+  memcpy(xs + sx, xv + sx + p, sizeof(double) * (size_t)(yd + zd));
+  memcpy(r1s, r1, sizeof(double) * (size_t)sx);
+  kkt_oracle_add_Kx_to_y(o, model, w, r1s, r2, r3, xs, ys);
+  for (int k = 0; k < sx; ++k)
+    yv[k] += ys[k];
+  for (int k = 0; k < yd + zd; ++k)
+    yv[sx + p + k] += ys[sx + k];
+  free(xs), free(ys), free(r1s);
+
+  const double *x_x = xv, *theta = xv + sx, *x_y = xv + sx + p, *x_z = x_y + yd;
+  double *y_x = yv, *y_theta = yv + sx, *y_y = yv + sx + p, *y_z = y_y + yd;
+  for (int i = 0; i < N; ++i) {
+    const int n = o->sd[i], c = o->ncd[i], g = o->ngd[i];
+    const double *Hxt = TBLK(o, tm, KKT_TH_NODE_DXDTH, i);
+    gemv_n(y_x + o->voff[KKT_X_STATE][i], Hxt, n, p, theta, 1.0);        /* :1036 */
+    gemv_t(y_theta, Hxt, n, p, x_x + o->voff[KKT_X_STATE][i]);            /* :1037 */
+    gemv_n(y_theta, TBLK(o, tm, KKT_TH_NODE_DTH2, i), p, p, theta, 1.0);  /* :1038-1040 */
+    gemv_n(y_y + o->voff[KKT_Y_NODE_C][i], TBLK(o, tm, KKT_TH_NODE_DC, i), c, p, theta, 1.0);
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_NODE_DC, i), c, p, x_y + o->voff[KKT_Y_NODE_C][i]);
+    gemv_n(y_z + o->voff[KKT_Z_NODE][i], TBLK(o, tm, KKT_TH_NODE_DG, i), g, p, theta, 1.0);
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_NODE_DG, i), g, p, x_z + o->voff[KKT_Z_NODE][i]);
+  }
+  for (int e = 0; e < E; ++e) {
+    const int parent = o->ws.edge_parents[e], child = o->ws.edge_children[e];
+    const int n = o->sd[parent], nc = o->sd[child], m = o->cd[e], c = o->ecd[e], g = o->egd[e];
+    const double *Hxt = TBLK(o, tm, KKT_TH_EDGE_DXDTH, e), *Hut = TBLK(o, tm, KKT_TH_EDGE_DUDTH, e);
+    gemv_n(y_x + o->voff[KKT_X_STATE][parent], Hxt, n, p, theta, 1.0);
+    gemv_n(y_x + o->voff[KKT_X_CONTROL][e], Hut, m, p, theta, 1.0);
+    gemv_t(y_theta, Hxt, n, p, x_x + o->voff[KKT_X_STATE][parent]);
+    gemv_t(y_theta, Hut, m, p, x_x + o->voff[KKT_X_CONTROL][e]);
+    gemv_n(y_theta, TBLK(o, tm, KKT_TH_EDGE_DTH2, e), p, p, theta, 1.0);
+    gemv_n(y_y + o->voff[KKT_Y_DYN][child], TBLK(o, tm, KKT_TH_EDGE_DDYN, e), nc, p, theta, 1.0);
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_EDGE_DDYN, e), nc, p, x_y + o->voff[KKT_Y_DYN][child]);
+    gemv_n(y_y + o->voff[KKT_Y_EDGE_C][e], TBLK(o, tm, KKT_TH_EDGE_DC, e), c, p, theta, 1.0);
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_EDGE_DC, e), c, p, x_y + o->voff[KKT_Y_EDGE_C][e]);
+    gemv_n(y_z + o->voff[KKT_Z_EDGE][e], TBLK(o, tm, KKT_TH_EDGE_DG, e), g, p, theta, 1.0);
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_EDGE_DG, e), g, p, x_z + o->voff[KKT_Z_EDGE][e]);
+  }
+  for (int d = 0; d < p; ++d) /* r1 on the theta block, :965-967 */
+    y_theta[d] += r1[sx + d] * theta[d];
 }

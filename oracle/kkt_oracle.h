@@ -2,14 +2,14 @@
  * kkt_oracle.h -- CPU restatement of the reference's Newton-KKT callbacks
  * (the caller either side of the Riccati path).  TEST INFRASTRUCTURE ONLY.
  *
- * Restates, in plain C99 on top of lqr_oracle.c, for theta_dim == 0:
+ * Restates, in plain C99 on top of lqr_oracle.c:
  *   CallbackProvider::factor            helpers.cpp:242-370
  *   CallbackProvider::solve             helpers.cpp:749-893 (single rhs)
  *   CallbackProvider::add_Kx_to_y       helpers.cpp:953-976
  *     add_Hx/Cx/CTx/Gx/GTx_to_y         helpers.cpp:978-1368
  * and the flattened variable ordering of populate_workspace_metadata
- * (types.cpp:24-64).  The theta (global variable) Schur complement
- * (helpers.cpp:372-412, 896-951) is not restated.
+ * (types.cpp:24-64); the theta (global variable) Schur complement
+ * (helpers.cpp:190-240, 372-407, 896-951) in the *_theta functions below.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.
@@ -17,7 +17,8 @@
  * Parity pinning: the reference's own tests of this path
  * (tests/variable_dimensions_test.cpp:135-181, 265-336) are re-expressed in
  * tests/test_kkt_oracle_reference.py (same model data, same regularization,
- * K * solution == rhs to 1e-9), and the solution is compared with an
+ * K * solution == rhs to 1e-9; :338-363 with theta_dim = 2 to 1e-8), and the
+ * solution is compared with an
  * independent numpy assembly + dense solve of the full KKT matrix
  * (oracle/dense_kkt.py: full_kkt_matrix).
  *
@@ -91,6 +92,44 @@ void kkt_oracle_add_Kx_to_y(const kkt_oracle *o, const double *model,
  * types.hpp:142-153): block `name` in "QMRqrcd" (d = dyn_r2) of node/edge
  * `index`; for tests of the condensation alone. */
 const double *kkt_oracle_lqr_block(const kkt_oracle *o, char name, int index);
+
+/*
+ * Global variables theta (Dimensions::theta_dim = p > 0): the Schur-complement
+ * path of CallbackProvider::factor (helpers.cpp:372-407, with
+ * form_theta_jacobian :190-240 and the multi-right-hand-side
+ * solve_stagewise_kkt_matrix :414-747), CallbackProvider::solve (:896-951) and
+ * the theta terms of add_*x_to_y (:1023-1066, 1128-1158, 1221-1249, 1285-1308,
+ * 1344-1367).  The multi-rhs block of the reference computes, column by column
+ * of J_theta, exactly the quantities of its single-rhs block (GEMM in place of
+ * GEMV), so it is restated as a loop over columns.
+ *
+ * Theta arena of ONE problem (doubles, column-major blocks, node i then edge i):
+ *   node i : d2L_dxdtheta (n x p) | dc_dtheta (c x p) | dg_dtheta (g x p) |
+ *            d2L_dtheta2 (p x p)
+ *   edge e : d2L_dxdtheta (np x p) | d2L_dudtheta (m x p) | ddyn_dtheta (nc x p) |
+ *            dc_dtheta (ce x p) | dg_dtheta (ge x p) | d2L_dtheta2 (p x p)
+ * Vectors with theta: x = [stagewise x | theta], i.e. b, sol = [x | theta | y | z];
+ * r1 has x_dim + p entries (theta last).
+ */
+enum {
+  KKT_TH_NODE_DXDTH = 0, KKT_TH_NODE_DC, KKT_TH_NODE_DG, KKT_TH_NODE_DTH2,
+  KKT_TH_EDGE_DXDTH, KKT_TH_EDGE_DUDTH, KKT_TH_EDGE_DDYN, KKT_TH_EDGE_DC, KKT_TH_EDGE_DG, KKT_TH_EDGE_DTH2,
+  KKT_TH_NUM_BLOCKS
+};
+#define KKT_ORACLE_THETA_SCHUR_FAILURE 7 /* helpers.cpp:404-407: LLT of the Schur complement failed */
+
+/* Enables theta_dim = p on an oracle (call once, before factor). */
+void kkt_oracle_set_theta(kkt_oracle *o, int theta_dim);
+/* which: 0 theta arena length */
+long kkt_oracle_theta_len(const kkt_oracle *o);
+long kkt_oracle_theta_offset(const kkt_oracle *o, int block, int index);
+int kkt_oracle_factor_theta(kkt_oracle *o, const double *model, const double *theta_model,
+                            const double *w, const double *r1, const double *r2, const double *r3);
+void kkt_oracle_solve_theta(kkt_oracle *o, const double *model, const double *theta_model,
+                            const double *b, double *sol);
+void kkt_oracle_add_Kx_to_y_theta(const kkt_oracle *o, const double *model, const double *theta_model,
+                                  const double *w, const double *r1, const double *r2, const double *r3,
+                                  const double *x, double *y);
 
 /* factor + solve of `batch` problems sharing the topology (arenas strided by
  * the per-problem lengths), OpenMP over problems with one handle per thread.

@@ -39,13 +39,34 @@ def initialize_model(dims):
     return dims.pack_model(nodes, edges)
 
 
+def initialize_theta_model(dims, theta_diagonal):
+    """The theta blocks of initialize_model (:93-98, 119-131)."""
+    p = dims.p
+    nodes, edges = [], []
+    for i in range(dims.N):
+        n, c, g = dims.sd[i], dims.ncd[i], dims.ngd[i]
+        nodes.append({"d2L_dxdtheta": _sequence((n, p), 0.0005 * (i + 1)),
+                      "dc_dtheta": _sequence((c, p), 0.001 * (i + 1)),
+                      "dg_dtheta": _sequence((g, p), -0.0007 * (i + 1)),
+                      "d2L_dtheta2": theta_diagonal * np.eye(p)})
+    for e in range(dims.E):
+        np_, nc, m = dims.sd[dims.parents[e]], dims.sd[dims.children[e]], dims.cd[e]
+        edges.append({"d2L_dxdtheta": _sequence((np_, p), 0.0004 * (e + 1)),
+                      "d2L_dudtheta": _sequence((m, p), -0.0003 * (e + 1)),
+                      "ddyn_dtheta": _sequence((nc, p), 0.0009 * (e + 1)),
+                      "dc_dtheta": _sequence((dims.ecd[e], p), 0.0008 * (e + 1)),
+                      "dg_dtheta": _sequence((dims.egd[e], p), -0.0006 * (e + 1)),
+                      "d2L_dtheta2": theta_diagonal * np.eye(p)})
+    return dims.pack_theta(nodes, edges)
+
+
 def regularization(dims):
-    """expect_kkt_solve, :144-151 and the rhs of :155-156."""
+    """expect_kkt_solve, :144-151 and the rhs of :155-156 (x_dim includes theta)."""
     w = np.full(dims.z_dim, 1.3)
     r2 = np.full(dims.y_dim, 0.9)
     r3 = np.full(dims.z_dim, 0.4)
-    r1 = 0.03 * np.arange(1, dims.x_dim + 1) + 0.2
-    rhs = 0.01 * np.arange(1, dims.kkt_dim + 1)
+    r1 = 0.03 * np.arange(1, dims.x_dim + dims.p + 1) + 0.2
+    rhs = 0.01 * np.arange(1, dims.full_dim + 1)
     return w, r1, r2, r3, rhs
 
 
@@ -63,6 +84,16 @@ REFERENCE_CASES = {
     "branch_zero_dim_root": dict(BRANCH, state_dims=[0, 1, 3], control_dims=[1, 2], node_c=[0, 0, 0],
                                  node_g=[0, 0, 0], edge_c=[0, 0], edge_g=[0, 0]),
 }
+
+
+# CallbackProvider.SolvesBranchedSystemWithSchurVariables, :338-363 (theta_dim = 2, tolerance 1e-8)
+SCHUR_CASE = dict(BRANCH, state_dims=[2, 1, 3], control_dims=[1, 2], node_c=[1, 0, 1], node_g=[0, 1, 1],
+                  edge_c=[1, 2], edge_g=[2, 1], theta_dim=2)
+
+
+def schur_case():
+    dims = KKTDims(**SCHUR_CASE)
+    return dims, initialize_model(dims), initialize_theta_model(dims, 6.0), regularization(dims)
 
 
 def reference_case(name):
@@ -107,11 +138,26 @@ def newton_kkt_problem(dims, seed, batch=None, r2_max=1e9):
                           "d2L_du2": spd(m, 1.0)})
         models.append(dims.pack_model(nodes, edges))
     model = np.stack(models)
+    thetas = []
+    if dims.p > 0:  # theta blocks of :184-236: 1e-3 N(0,1) couplings, d2L_dtheta2 = G^T G + 100 I on the last node
+        pp = dims.p
+        for _ in range(count):
+            tn = [{"d2L_dxdtheta": 1e-3 * rng.standard_normal((dims.sd[i], pp)),
+                   "dc_dtheta": 1e-3 * rng.standard_normal((dims.ncd[i], pp)),
+                   "dg_dtheta": 1e-3 * rng.standard_normal((dims.ngd[i], pp)),
+                   "d2L_dtheta2": spd(pp, 100.0) if i == dims.E else np.zeros((pp, pp))} for i in range(dims.N)]
+            te = [{"d2L_dxdtheta": 1e-3 * rng.standard_normal((dims.sd[dims.parents[e]], pp)),
+                   "d2L_dudtheta": 1e-3 * rng.standard_normal((dims.cd[e], pp)),
+                   "ddyn_dtheta": 1e-3 * rng.standard_normal((dims.sd[dims.children[e]], pp)),
+                   "dc_dtheta": 1e-3 * rng.standard_normal((dims.ecd[e], pp)),
+                   "dg_dtheta": 1e-3 * rng.standard_normal((dims.egd[e], pp)),
+                   "d2L_dtheta2": np.zeros((pp, pp))} for e in range(dims.E)]
+            thetas.append(dims.pack_theta(tn, te))
     logu = lambda lo, hi, size: np.exp(np.log(lo) + (np.log(hi) - np.log(lo)) * rng.random(size))
     r2 = logu(1e-3, r2_max, (count, dims.y_dim))
     w = logu(1e-2, 1e3, (count, dims.z_dim))
     r3 = logu(1e-3, 1e1, (count, dims.z_dim))
-    r1 = np.full((count, dims.x_dim), 1e-8)
-    rhs = rng.standard_normal((count, dims.kkt_dim))
-    out = (model, w, r1, r2, r3, rhs)
+    r1 = np.full((count, dims.x_dim + dims.p), 1e-8)
+    rhs = rng.standard_normal((count, dims.full_dim))
+    out = (model, w, r1, r2, r3, rhs) + ((np.stack(thetas),) if dims.p > 0 else ())
     return out if batch is not None else tuple(a[0] for a in out)

@@ -148,3 +148,36 @@ def test_batch_entry_matches_single():
     for p in (0, 5):
         assert o.factor(model[p], w[p], r1[p], r2[p], r3[p]) == 0
         np.testing.assert_array_equal(sol[p], o.solve(model[p], rhs[p]))
+
+
+def test_reference_schur_variables():
+    """CallbackProvider.SolvesBranchedSystemWithSchurVariables (:338-363): theta_dim = 2,
+    d2L_dtheta2 = 6 I, K * solution == rhs to 1e-8 through add_Kx_to_y."""
+    dims, model, theta_model, (w, r1, r2, r3, rhs) = rk.schur_case()
+    o = KKTOracle(dims)
+    assert o.factor_theta(model, theta_model, w, r1, r2, r3) == 0
+    sol = o.solve_theta(model, theta_model, rhs)
+    product = o.add_Kx_to_y_theta(model, theta_model, w, r1, r2, r3, sol)
+    assert np.linalg.norm(product - rhs) < 1e-8  # the reference's tolerance, :362
+    K = dense_kkt_matrix(dims, model, w, r1, r2, r3, theta_model)
+    assert K.shape == (dims.full_dim, dims.full_dim)
+    np.testing.assert_allclose(K, K.T, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(product, K @ sol, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sol, np.linalg.solve(K, rhs), rtol=1e-9, atol=1e-11)
+    # Schur complement not positive definite -> factor() is false (helpers.cpp:404-407)
+    bad = rk.initialize_theta_model(dims, -50.0)
+    assert o.factor_theta(model, bad, w, r1, r2, r3) == 7
+
+
+def test_theta_on_a_benchmark_chain():
+    """NewtonKKTProblem(n, m, T, p) of newton_kkt_benchmark.cpp:58-262 (theta variant)."""
+    base = rk.newton_kkt_dims(6, 2, 10)
+    dims = KKTDims(base.parents, base.children, base.sd, base.cd, base.ncd, base.ngd, base.ecd, base.egd,
+                   theta_dim=4)
+    model, w, r1, r2, r3, rhs, theta_model = rk.newton_kkt_problem(dims, seed=9, r2_max=1e2)
+    o = KKTOracle(dims)
+    assert o.factor_theta(model, theta_model, w, r1, r2, r3) == 0
+    sol = o.solve_theta(model, theta_model, rhs)
+    K = dense_kkt_matrix(dims, model, w, r1, r2, r3, theta_model)
+    dense = np.linalg.solve(K, rhs)
+    assert np.linalg.norm(sol - dense) <= 1e-8 * np.linalg.norm(dense)
