@@ -2,7 +2,7 @@
  * sip_kkt_amd.h -- C ABI of the batched Newton-KKT step on MI355X (gfx950):
  * the caller either side of the Riccati path (SURVEY.md section 8, rows f1
  * and f4), device-resident, for `batch` problems that share one topology and
- * dimension table (theta_dim == 0).
+ * dimension table.
  *
  * Replaces, of /root/reference/sip_optimal_control (class CallbackProvider,
  * helpers.hpp:7-33):
@@ -15,8 +15,9 @@
  * (sip_lqr_amd.h): uniform chains use the packed chain layout and its fused
  * kernels, everything else the general tree engine.
  *
- * Not covered: global variables theta (theta_dim > 0: the multi-RHS solve and
- * Schur complement, helpers.cpp:372-747, 896-951).
+ * Global variables theta (theta_dim > 0: the Schur complement and its
+ * multi-right-hand-side solve, helpers.cpp:372-747, 896-951): the *_theta
+ * entry points at the end of this header.
  *
  * Data (all double, device memory, problem p at p * per-problem length):
  *
@@ -157,6 +158,63 @@ int sip_kkt_add_Kx_to_y(const sip_kkt_plan *plan, const double *d_model,
                         const double *d_w, const double *d_r1,
                         const double *d_r2, const double *d_r3,
                         const double *d_x, double *d_y, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Global variables theta (Dimensions::theta_dim = p > 0; SURVEY.md section 8
+ * row f2): the Schur complement on theta around the stagewise solve.
+ *
+ * Replaces, for p > 0: form_theta_jacobian (helpers.cpp:190-240), the theta
+ * part of CallbackProvider::factor (:372-407) with its multi-right-hand-side
+ * stagewise solve (:414-747), CallbackProvider::solve (:896-951) and the
+ * theta terms of add_*x_to_y (:1023-1066, 1128-1158, 1221-1249, 1285-1308,
+ * 1344-1367).  K^-1 J_theta runs as p launches of the plan's solve path, one
+ * per column (the reference's multi-rhs block computes the same quantities
+ * column by column, GEMM in place of GEMV).
+ *
+ * theta arena [sip_kkt_theta_len(plan)] per problem (doubles, column-major
+ * blocks, node i then edge i):
+ *   node i : d2L_dxdtheta (n x p) | dc_dtheta (c x p) | dg_dtheta (g x p) |
+ *            d2L_dtheta2 (p x p)
+ *   edge e : d2L_dxdtheta (np x p) | d2L_dudtheta (m x p) | ddyn_dtheta (nc x p) |
+ *            dc_dtheta (ce x p) | dg_dtheta (ge x p) | d2L_dtheta2 (p x p)
+ * Vectors: x = [stagewise x | theta]: r1 has x_dim + p entries, b and sol are
+ * [x | theta | y | z] (x_dim + p + y_dim + z_dim).  sip_kkt_len() keeps
+ * reporting the stagewise x_dim.
+ * ---------------------------------------------------------------------- */
+enum {
+  SIP_KKT_TH_NODE_D2L_DXDTHETA = 0, SIP_KKT_TH_NODE_DC_DTHETA, SIP_KKT_TH_NODE_DG_DTHETA,
+  SIP_KKT_TH_NODE_D2L_DTHETA2, SIP_KKT_TH_EDGE_D2L_DXDTHETA, SIP_KKT_TH_EDGE_D2L_DUDTHETA,
+  SIP_KKT_TH_EDGE_DDYN_DTHETA, SIP_KKT_TH_EDGE_DC_DTHETA, SIP_KKT_TH_EDGE_DG_DTHETA,
+  SIP_KKT_TH_EDGE_D2L_DTHETA2, SIP_KKT_TH_NUM_BLOCKS
+};
+/* status[p] when the LLT of the theta Schur complement fails (helpers.cpp:404-407) */
+#define SIP_KKT_THETA_SCHUR_FAILURE 7
+
+/* Declares theta_dim = p (> 0) on a valid plan; call once, before the *_theta
+ * entry points (Dimensions::theta_dim, lqr.hpp:25). */
+int sip_kkt_plan_set_theta(sip_kkt_plan *plan, int theta_dim);
+size_t sip_kkt_theta_len(const sip_kkt_plan *plan);
+size_t sip_kkt_theta_offset(const sip_kkt_plan *plan, int block, int index);
+/* Bytes of the extra device scratch: J_theta, K^-1 J_theta
+ * (Workspace::RegularizedLQRData::theta_jacobian / theta_solution,
+ * types.hpp:174-175), the Schur factor, theta_rhs and the stagewise rhs /
+ * solution (types.hpp:176-179), for the whole batch. */
+size_t sip_kkt_theta_work_bytes(const sip_kkt_plan *plan);
+
+int sip_kkt_factor_theta(const sip_kkt_plan *plan, const double *d_model,
+                         const double *d_theta_model, const double *d_w,
+                         const double *d_r1, const double *d_r2,
+                         const double *d_r3, void *d_work, void *d_theta_work,
+                         int32_t *d_status, void *stream);
+int sip_kkt_solve_theta(const sip_kkt_plan *plan, const double *d_model,
+                        const double *d_theta_model, const double *d_b,
+                        double *d_sol, void *d_work, void *d_theta_work,
+                        const int32_t *d_status, void *stream);
+int sip_kkt_add_Kx_to_y_theta(const sip_kkt_plan *plan, const double *d_model,
+                              const double *d_theta_model, const double *d_w,
+                              const double *d_r1, const double *d_r2,
+                              const double *d_r3, const double *d_x,
+                              double *d_y, void *stream);
 
 #ifdef __cplusplus
 }

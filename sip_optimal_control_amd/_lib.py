@@ -70,6 +70,13 @@ _SIGNATURES = {
     "sip_kkt_solve": (ctypes.c_int, [_P] * 7),
     "sip_kkt_factor_solve": (ctypes.c_int, [_P] * 11),
     "sip_kkt_add_Kx_to_y": (ctypes.c_int, [_P] * 9),
+    "sip_kkt_plan_set_theta": (ctypes.c_int, [_P, ctypes.c_int]),
+    "sip_kkt_theta_len": (ctypes.c_size_t, [_P]),
+    "sip_kkt_theta_offset": (ctypes.c_size_t, [_P, ctypes.c_int, ctypes.c_int]),
+    "sip_kkt_theta_work_bytes": (ctypes.c_size_t, [_P]),
+    "sip_kkt_factor_theta": (ctypes.c_int, [_P] * 11),
+    "sip_kkt_solve_theta": (ctypes.c_int, [_P] * 9),
+    "sip_kkt_add_Kx_to_y_theta": (ctypes.c_int, [_P] * 10),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -30,7 +30,8 @@ enum Block {
 
 struct Meta {
   int E, N, root;
-  int x_dim, y_dim, z_dim;
+  int x_dim, y_dim, z_dim; // stagewise (theta excluded)
+  int theta_dim;           // 0 except for apply_kernel on [x | theta | y | z] vectors
   long model_len, in0_len, in1_len, out_len;
   // dimension tables and traversal (per node / per edge)
   const int *sd, *cd, *ncd, *ngd, *ecd, *egd, *parent, *child, *in_edge, *child_offsets, *child_edges;
@@ -609,12 +610,13 @@ apply_kernel(const Meta mt, const double *__restrict__ model_all, const double *
   const int item = blockIdx.x - (unsigned)(p * items);
   if (p >= batch)
     return;
-  const long kkt = (long)mt.x_dim + mt.y_dim + mt.z_dim;
+  const int xt = mt.x_dim + mt.theta_dim; // theta (if any) sits between x and y
+  const long kkt = (long)xt + mt.y_dim + mt.z_dim;
   const double *model = model_all + p * mt.model_len;
-  const double *w = w_all + p * mt.z_dim, *r1 = r1_all + p * mt.x_dim, *r2 = r2_all + p * mt.y_dim;
+  const double *w = w_all + p * mt.z_dim, *r1 = r1_all + p * xt, *r2 = r2_all + p * mt.y_dim;
   const double *r3 = r3_all + p * mt.z_dim;
-  const double *x_x = x_all + p * kkt, *x_y = x_x + mt.x_dim, *x_z = x_y + mt.y_dim;
-  double *y_x = y_all + p * kkt, *y_y = y_x + mt.x_dim, *y_z = y_y + mt.y_dim;
+  const double *x_x = x_all + p * kkt, *x_y = x_x + xt, *x_z = x_y + mt.y_dim;
+  double *y_x = y_all + p * kkt, *y_y = y_x + xt, *y_z = y_y + mt.y_dim;
   const int tid = threadIdx.x;
   if (item < mt.N) {
     const int i = item, n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];

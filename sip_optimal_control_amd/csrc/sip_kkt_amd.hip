@@ -15,6 +15,7 @@
 #include "generic_plan.hpp"
 #include "kkt_chain_kernels.hpp"
 #include "kkt_kernels.hpp"
+#include "kkt_theta_kernels.hpp"
 
 struct sip_kkt_plan {
   int64_t batch = 0;
@@ -37,6 +38,12 @@ struct sip_kkt_plan {
   bool chain_kernels = false; // uniform chain: arithmetic-offset kernels (kkt_chain_kernels.hpp)
   sipamd::kkt::ChainKkt ck{};
   size_t lds_chain_condense = 0, lds_chain_recover = 0;
+  // theta (sip_kkt_plan_set_theta)
+  int theta_dim = 0;
+  std::vector<long> toff[sipamd::kkt::TH_NUM_BLOCKS];
+  long theta_len = 0;
+  void *d_theta_longs = nullptr;
+  sipamd::kkt::ThetaMeta theta_meta{};
   bool staged = false; // LDS-staged kernels (false: items too large for LDS, or SIP_KKT_VARIANT=direct)
   size_t lds_condense = 0, lds_rhs = 0, lds_recover = 0;
   std::string name;
@@ -50,6 +57,8 @@ struct sip_kkt_plan {
       (void)hipFree(d_ints);
     if (d_longs)
       (void)hipFree(d_longs);
+    if (d_theta_longs)
+      (void)hipFree(d_theta_longs);
   }
 };
 
@@ -575,6 +584,165 @@ int sip_kkt_add_Kx_to_y(const sip_kkt_plan *p, const double *d_model, const doub
   hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, (hipStream_t)stream,
                      p->meta, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
   return report(hipGetLastError(), "sip_kkt_add_Kx_to_y");
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// theta (global variables): Schur complement around the stagewise solve
+// ---------------------------------------------------------------------------
+namespace {
+
+struct ThetaRegions {
+  double *J, *KJ, *S, *rhs_sw, *sol_sw;
+};
+ThetaRegions theta_regions(const sip_kkt_plan *p, void *theta_work) {
+  const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, B = (size_t)p->batch;
+  char *w = (char *)theta_work;
+  ThetaRegions r;
+  size_t cur = 0;
+  r.J = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt * p->theta_dim);
+  r.KJ = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt * p->theta_dim);
+  r.S = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * p->theta_dim * p->theta_dim);
+  r.rhs_sw = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt);
+  r.sol_sw = (double *)(w + cur);
+  return r;
+}
+
+} // namespace
+
+extern "C" {
+
+int sip_kkt_plan_set_theta(sip_kkt_plan *p, int theta_dim) {
+  if (p == nullptr || theta_dim < 1 || p->theta_dim != 0 || p->input_status != SIP_KKT_SUCCESS)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  using namespace sipamd::kkt;
+  const int E = p->E, N = p->N, th = theta_dim;
+  for (auto &v : p->toff)
+    v.assign(N, 0);
+  long at = 0;
+  for (int i = 0; i < N; ++i) {
+    p->toff[TH_N_X][i] = at, at += (long)p->sd[i] * th;
+    p->toff[TH_N_C][i] = at, at += (long)p->ncd[i] * th;
+    p->toff[TH_N_G][i] = at, at += (long)p->ngd[i] * th;
+    p->toff[TH_N_TT][i] = at, at += (long)th * th;
+    if (i < E) {
+      const int e = i;
+      p->toff[TH_E_X][e] = at, at += (long)p->sd[p->parents[e]] * th;
+      p->toff[TH_E_U][e] = at, at += (long)p->cd[e] * th;
+      p->toff[TH_E_DYN][e] = at, at += (long)p->sd[p->children[e]] * th;
+      p->toff[TH_E_C][e] = at, at += (long)p->ecd[e] * th;
+      p->toff[TH_E_G][e] = at, at += (long)p->egd[e] * th;
+      p->toff[TH_E_TT][e] = at, at += (long)th * th;
+    }
+  }
+  std::vector<long> longs;
+  size_t where[TH_NUM_BLOCKS];
+  for (int b = 0; b < TH_NUM_BLOCKS; ++b) {
+    where[b] = longs.size();
+    longs.insert(longs.end(), p->toff[b].begin(), p->toff[b].end());
+  }
+  hipError_t he = hipSetDevice(p->device);
+  if (he == hipSuccess)
+    he = hipMalloc(&p->d_theta_longs, longs.size() * sizeof(long));
+  if (he == hipSuccess)
+    he = hipMemcpy(p->d_theta_longs, longs.data(), longs.size() * sizeof(long), hipMemcpyHostToDevice);
+  if (he != hipSuccess)
+    return report(he, "sip_kkt_plan_set_theta");
+  p->theta_len = at, p->theta_dim = th;
+  p->theta_meta.p = th, p->theta_meta.theta_len = at;
+  for (int b = 0; b < TH_NUM_BLOCKS; ++b)
+    p->theta_meta.to[b] = (const long *)p->d_theta_longs + where[b];
+  return SIP_LQR_OK;
+}
+
+size_t sip_kkt_theta_len(const sip_kkt_plan *p) { return (p && p->theta_dim > 0) ? (size_t)p->theta_len : 0; }
+
+size_t sip_kkt_theta_offset(const sip_kkt_plan *p, int block, int index) {
+  if (p == nullptr || p->theta_dim < 1 || block < 0 || block >= SIP_KKT_TH_NUM_BLOCKS || index < 0 ||
+      index >= (block <= SIP_KKT_TH_NODE_D2L_DTHETA2 ? p->N : p->E))
+    return (size_t)-1;
+  return (size_t)p->toff[block][index];
+}
+
+size_t sip_kkt_theta_work_bytes(const sip_kkt_plan *p) {
+  if (p == nullptr || p->theta_dim < 1)
+    return 0;
+  const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, B = (size_t)p->batch, th = (size_t)p->theta_dim;
+  return 2 * align256(sizeof(double) * B * skkt * th) + align256(sizeof(double) * B * th * th) +
+         2 * align256(sizeof(double) * B * skkt);
+}
+
+int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const double *d_theta, const double *d_w,
+                         const double *d_r1, const double *d_r2, const double *d_r3, void *d_work,
+                         void *d_theta_work, int32_t *d_status, void *stream) {
+  if (p == nullptr || p->theta_dim < 1 || !d_theta || !d_theta_work || !d_r1)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  // r1 of problem q starts at q * (x_dim + p); the condensation kernels index r1 with the
+  // stagewise stride x_dim, so they get a compacted copy (theta entries dropped).
+  hipStream_t s = (hipStream_t)stream;
+  const ThetaRegions t = theta_regions(p, d_theta_work);
+  const int sx = p->x_dim, th = p->theta_dim;
+  const long skkt = (long)sx + p->y_dim + p->z_dim;
+  // compact r1 (drop the theta entries) into rhs_sw's space (free until solve)
+  hipError_t e = hipMemcpy2DAsync(t.rhs_sw, sizeof(double) * (size_t)sx, d_r1, sizeof(double) * (size_t)(sx + th),
+                                  sizeof(double) * (size_t)sx, (size_t)p->batch, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess)
+    return report(e, "sip_kkt_factor_theta(r1)");
+  int rc = sip_kkt_factor(p, d_model, d_w, t.rhs_sw, d_r2, d_r3, d_work, d_status, stream);
+  if (rc != SIP_LQR_OK)
+    return rc;
+  hipLaunchKernelGGL(sipamd::kkt::theta_jacobian_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta,
+                     p->theta_meta, d_theta, t.J, (long)p->batch);
+  if ((e = hipGetLastError()) != hipSuccess)
+    return report(e, "sip_kkt_factor_theta(jacobian)");
+  for (int col = 0; col < th; ++col) { // K^-1 J_theta, one column per launch (helpers.cpp:387)
+    rc = sip_kkt_solve(p, d_model, t.J + (size_t)col * p->batch * skkt, t.KJ + (size_t)col * p->batch * skkt, d_work,
+                       d_status, stream);
+    if (rc != SIP_LQR_OK)
+      return rc;
+  }
+  hipLaunchKernelGGL(sipamd::kkt::theta_schur_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
+                     sizeof(double) * (size_t)th * th, s, p->meta, p->theta_meta, d_theta, d_r1, t.J, t.KJ, t.S,
+                     d_status, (long)p->batch, (int)SIP_KKT_THETA_SCHUR_FAILURE);
+  return report(hipGetLastError(), "sip_kkt_factor_theta(schur)");
+}
+
+int sip_kkt_solve_theta(const sip_kkt_plan *p, const double *d_model, const double *d_theta, const double *d_b,
+                        double *d_sol, void *d_work, void *d_theta_work, const int32_t *d_status, void *stream) {
+  if (p == nullptr || p->theta_dim < 1 || !d_theta || !d_theta_work || !d_b || !d_sol || !d_status)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const ThetaRegions t = theta_regions(p, d_theta_work);
+  const int sx = p->x_dim, th = p->theta_dim;
+  const long skkt = (long)sx + p->y_dim + p->z_dim;
+  hipLaunchKernelGGL(sipamd::kkt::theta_strip_kernel, dim3((unsigned)((p->batch * skkt + 255) / 256)), dim3(256), 0, s,
+                     d_b, t.rhs_sw, sx, th, skkt, (long)p->batch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return report(e, "sip_kkt_solve_theta(strip)");
+  const int rc = sip_kkt_solve(p, d_model, t.rhs_sw, t.sol_sw, d_work, d_status, stream);
+  if (rc != SIP_LQR_OK)
+    return rc;
+  hipLaunchKernelGGL(sipamd::kkt::theta_finish_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
+                     sizeof(double) * (size_t)th, s, p->meta, p->theta_meta, d_b, t.J, t.KJ, t.S, t.sol_sw, d_sol,
+                     d_status, (long)p->batch);
+  return report(hipGetLastError(), "sip_kkt_solve_theta(finish)");
+}
+
+int sip_kkt_add_Kx_to_y_theta(const sip_kkt_plan *p, const double *d_model, const double *d_theta,
+                              const double *d_w, const double *d_r1, const double *d_r2, const double *d_r3,
+                              const double *d_x, double *d_y, void *stream) {
+  if (p == nullptr || p->theta_dim < 1 || !d_theta || !d_r1 || !d_x || !d_y)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  sipamd::kkt::Meta wide = p->meta; // the stagewise operator on [x | theta | y | z] vectors
+  wide.theta_dim = p->theta_dim;
+  hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, wide, d_model, d_w,
+                     d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
+  hipLaunchKernelGGL(sipamd::kkt::apply_theta_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB), 0, s, p->meta,
+                     p->theta_meta, d_theta, d_r1, d_x, d_y, (long)p->batch);
+  return report(hipGetLastError(), "sip_kkt_add_Kx_to_y_theta");
 }
 
 } // extern "C"

@@ -30,7 +30,7 @@ def _ints(values):
 
 class BatchedNewtonKKT:
     def __init__(self, parents, children, state_dims, control_dims, node_c_dims=None, node_g_dims=None,
-                 edge_c_dims=None, edge_g_dims=None, batch=1, root=0, device="cuda:0"):
+                 edge_c_dims=None, edge_g_dims=None, batch=1, root=0, device="cuda:0", theta_dim=0):
         self._lib = load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -47,6 +47,14 @@ class BatchedNewtonKKT:
         self.kkt_dim = self.x_dim + self.y_dim + self.z_dim
         self.kernel_name = self._lib.sip_kkt_kernel_name(h).decode()
         self.work = torch.empty(max(1, self._lib.sip_kkt_work_bytes(h)), dtype=torch.uint8, device=self.device)
+        self.theta_dim = int(theta_dim)
+        self.theta_len = 0
+        if self.theta_dim > 0:  # global variables: x = [stagewise x | theta]
+            _check(self._lib.sip_kkt_plan_set_theta(h, self.theta_dim), "sip_kkt_plan_set_theta")
+            self.theta_len = self._lib.sip_kkt_theta_len(h)
+            self.theta_work = torch.empty(max(1, self._lib.sip_kkt_theta_work_bytes(h)), dtype=torch.uint8,
+                                          device=self.device)
+        self.full_dim = self.kkt_dim + self.theta_dim
         self.status = torch.full((self.batch,), -1, dtype=torch.int32, device=self.device)
 
     def model_offset(self, block, index):
@@ -105,6 +113,43 @@ class BatchedNewtonKKT:
                                              self._ptr(r1, self.x_dim), self._ptr(r2, self.y_dim),
                                              self._ptr(r3, self.z_dim), self._ptr(x, self.kkt_dim),
                                              self._ptr(y, self.kkt_dim), self._stream()), "sip_kkt_add_Kx_to_y")
+        return y
+
+    # ---- theta_dim > 0: r1 is [batch, x_dim + p], b / sol / x / y are [batch, full_dim] ----
+    def theta_offset(self, block, index):
+        off = self._lib.sip_kkt_theta_offset(self._plan, block, index)
+        if off == ctypes.c_size_t(-1).value:
+            raise IndexError((block, index))
+        return off
+
+    def factor_theta(self, model, theta_model, w, r1, r2, r3):
+        _check(self._lib.sip_kkt_factor_theta(self._plan, self._ptr(model, self.model_len),
+                                              self._ptr(theta_model, self.theta_len), self._ptr(w, self.z_dim),
+                                              self._ptr(r1, self.x_dim + self.theta_dim), self._ptr(r2, self.y_dim),
+                                              self._ptr(r3, self.z_dim), self.work.data_ptr(),
+                                              self.theta_work.data_ptr(), self.status.data_ptr(), self._stream()),
+               "sip_kkt_factor_theta")
+        return self.status
+
+    def solve_theta(self, model, theta_model, b, sol=None):
+        if sol is None:
+            sol = torch.zeros(self.batch, self.full_dim, dtype=torch.float64, device=self.device)
+        _check(self._lib.sip_kkt_solve_theta(self._plan, self._ptr(model, self.model_len),
+                                             self._ptr(theta_model, self.theta_len), self._ptr(b, self.full_dim),
+                                             self._ptr(sol, self.full_dim), self.work.data_ptr(),
+                                             self.theta_work.data_ptr(), self.status.data_ptr(), self._stream()),
+               "sip_kkt_solve_theta")
+        return sol
+
+    def add_Kx_to_y_theta(self, model, theta_model, w, r1, r2, r3, x, y=None):
+        if y is None:
+            y = torch.zeros(self.batch, self.full_dim, dtype=torch.float64, device=self.device)
+        _check(self._lib.sip_kkt_add_Kx_to_y_theta(self._plan, self._ptr(model, self.model_len),
+                                                   self._ptr(theta_model, self.theta_len), self._ptr(w, self.z_dim),
+                                                   self._ptr(r1, self.x_dim + self.theta_dim),
+                                                   self._ptr(r2, self.y_dim), self._ptr(r3, self.z_dim),
+                                                   self._ptr(x, self.full_dim), self._ptr(y, self.full_dim),
+                                                   self._stream()), "sip_kkt_add_Kx_to_y_theta")
         return y
 
     def close(self):

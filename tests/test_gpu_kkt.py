@@ -20,7 +20,7 @@ REL = 1e-9
 def _make(dims, batch):
     from sip_optimal_control_amd import BatchedNewtonKKT
     return BatchedNewtonKKT(dims.parents, dims.children, dims.sd, dims.cd, dims.ncd, dims.ngd, dims.ecd, dims.egd,
-                            batch=batch, root=dims.root)
+                            batch=batch, root=dims.root, theta_dim=dims.p)
 
 
 def _dev(*arrays):
@@ -235,3 +235,57 @@ def test_condensation_variants_agree_bitwise(monkeypatch):
     monkeypatch.delenv("SIP_KKT_VARIANT")
     sol_s, _ = _make(tdims, 1).factor_solve(*td)
     assert torch.equal(sol_d, sol_s)
+
+
+def test_theta_schur_reference_case():
+    """CallbackProvider.SolvesBranchedSystemWithSchurVariables (variable_dimensions_test.cpp:338-363):
+    theta_dim = 2 on the branched tree; K * solution == rhs to 1e-8, and agreement with the oracle."""
+    dims, model, theta_model, (w, r1, r2, r3, rhs) = rk.schur_case()
+    batch = 3
+    mb, tb, wb, r1b, r2b, r3b, rb = _batchify(batch, model, theta_model, w, r1, r2, r3, rhs)
+    kkt = _make(dims, batch)
+    assert kkt.theta_len == dims.theta_len and kkt.full_dim == dims.full_dim
+    from oracle.kkt import THETA_EDGE_BLOCKS, THETA_NODE_BLOCKS
+    for b, name in enumerate(THETA_NODE_BLOCKS):
+        assert [kkt.theta_offset(b, i) for i in range(dims.N)] == dims.theta_node_off[name]
+    for b, name in enumerate(THETA_EDGE_BLOCKS):
+        assert [kkt.theta_offset(len(THETA_NODE_BLOCKS) + b, e) for e in range(dims.E)] == dims.theta_edge_off[name]
+    d = _dev(mb, tb, wb, r1b, r2b, r3b, rb)
+    assert kkt.factor_theta(*d[:6]).cpu().tolist() == [0] * batch
+    sol = kkt.solve_theta(d[0], d[1], d[6])
+    prod = kkt.add_Kx_to_y_theta(*d[:6], sol).cpu().numpy()
+    sol = sol.cpu().numpy()
+    o = KKTOracle(dims)
+    for p in range(batch):
+        assert o.factor_theta(mb[p], tb[p], wb[p], r1b[p], r2b[p], r3b[p]) == 0
+        ref = o.solve_theta(mb[p], tb[p], rb[p])
+        assert np.abs(sol[p] - ref).max() <= REL * max(1.0, np.abs(ref).max())
+        assert np.linalg.norm(prod[p] - rb[p]) < 1e-8  # the reference's tolerance, :362
+        K = dense_kkt_matrix(dims, mb[p], wb[p], r1b[p], r2b[p], r3b[p], tb[p])
+        np.testing.assert_allclose(prod[p], K @ sol[p], rtol=0, atol=1e-12)
+    # Schur complement not positive definite on one problem -> status 7, its sol untouched
+    bad = np.stack([tb[0], rk.initialize_theta_model(dims, -50.0), tb[2]])
+    db = _dev(bad)[0]
+    assert kkt.factor_theta(d[0], db, *d[2:6]).cpu().tolist() == [0, 7, 0]
+    sentinel = torch.full((batch, dims.full_dim), 3.0, dtype=torch.float64, device="cuda")
+    out = kkt.solve_theta(d[0], db, d[6], sol=sentinel).cpu().numpy()
+    assert (out[1] == 3.0).all() and np.abs(out[0] - sol[0]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("n,m,T,p", [(6, 2, 10, 4), (12, 4, 20, 8)])
+def test_theta_on_benchmark_chains(n, m, T, p):
+    """NewtonKKTProblem(n, m, T, p) (newton_kkt_benchmark.cpp:58-262, the Theta benchmarks)."""
+    base = rk.newton_kkt_dims(n, m, T)
+    dims = rk.KKTDims(base.parents, base.children, base.sd, base.cd, base.ncd, base.ngd, base.ecd, base.egd,
+                      theta_dim=p)
+    batch = 4
+    model, w, r1, r2, r3, rhs, theta_model = rk.newton_kkt_problem(dims, seed=7 + n, batch=batch, r2_max=1e2)
+    kkt = _make(dims, batch)
+    d = _dev(model, theta_model, w, r1, r2, r3, rhs)
+    assert kkt.factor_theta(*d[:6]).cpu().tolist() == [0] * batch
+    sol = kkt.solve_theta(d[0], d[1], d[6]).cpu().numpy()
+    o = KKTOracle(dims)
+    for q in range(batch):
+        assert o.factor_theta(model[q], theta_model[q], w[q], r1[q], r2[q], r3[q]) == 0
+        ref = o.solve_theta(model[q], theta_model[q], rhs[q])
+        assert np.abs(sol[q] - ref).max() <= 1e-8 * np.abs(ref).max()
