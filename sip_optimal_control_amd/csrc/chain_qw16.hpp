@@ -186,6 +186,13 @@ __device__ __forceinline__ bool node_factor(const double (&V)[N], const double d
 #ifndef SIP_LQR_NT_IN
 #define SIP_LQR_NT_IN 2
 #endif
+// rollout: re-read of A|B and delta / read of the gains and the spill (last use)
+#ifndef SIP_LQR_NT_FAB
+#define SIP_LQR_NT_FAB SIP_LQR_NT_IN
+#endif
+#ifndef SIP_LQR_NT_FSP
+#define SIP_LQR_NT_FSP 0
+#endif
 typedef __attribute__((address_space(3))) char lds_char;
 typedef const __attribute__((address_space(3))) double lds_cdouble;
 
@@ -681,13 +688,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     dma_fd.init(lane, (unsigned)(mats_len * 8), max_rel);
   }
   auto issue_forward = [&](const int i, lds_char *buf) {
-    dma_fa.template issue<SIP_LQR_NT_IN>((const char *)(mats + p0 * mats_len + (long)i * STG + L::NODE),
+    dma_fa.template issue<SIP_LQR_NT_FAB>((const char *)(mats + p0 * mats_len + (long)i * STG + L::NODE),
                  buf, lane);
-    dma_fg.issue((const char *)(gains + p0 * gains_len + (long)i * L::GAIN),
+    dma_fg.template issue<SIP_LQR_NT_FSP>((const char *)(gains + p0 * gains_len + (long)i * L::GAIN),
                  buf + C::FA::BYTES, lane);
-    dma_fw.issue((const char *)(wsp + p0 * ws_len + (long)(i + 1) * WSN),
+    dma_fw.template issue<SIP_LQR_NT_FSP>((const char *)(wsp + p0 * ws_len + (long)(i + 1) * WSN),
                  buf + C::FA::BYTES + C::FG::BYTES, lane);
-    dma_fd.template issue<SIP_LQR_NT_IN>(
+    dma_fd.template issue<SIP_LQR_NT_FAB>(
         (const char *)(mats + p0 * mats_len + (long)(i + 1) * STG + N * N),
         buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES, lane);
   };

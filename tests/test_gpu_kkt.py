@@ -289,3 +289,41 @@ def test_theta_on_benchmark_chains(n, m, T, p):
         assert o.factor_theta(model[q], theta_model[q], w[q], r1[q], r2[q], r3[q]) == 0
         ref = o.solve_theta(model[q], theta_model[q], rhs[q])
         assert np.abs(sol[q] - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+def test_full_size_properties():
+    """Batch 4096 at the f1 benchmark shape (n=12, m=4, T=50, c=6, g=8): size-independent
+    properties instead of an oracle pass -- K * sol == rhs through the GPU operator, linearity of
+    solve in the right-hand side, idempotence of a repeated factor+solve, and a sampled oracle check."""
+    from sip_optimal_control_amd import BatchedNewtonKKT, synthetic
+    n, m, T, batch = 12, 4, 50, 4096
+    c, g = n // 2, 2 * m
+    dd = dict(parents=list(range(T)), children=list(range(1, T + 1)), state_dims=[n] * (T + 1),
+              control_dims=[m] * T, node_c_dims=[0] * T + [c], node_g_dims=[0] * T + [g],
+              edge_c_dims=[c] * T, edge_g_dims=[g] * T)
+    kkt = BatchedNewtonKKT(batch=batch, **dd)
+    model, w, r1, r2, r3, rhs = synthetic.make_newton_kkt_batch(kkt, seed=5, r2_max=1e2, **dd)
+    sol, status = kkt.factor_solve(model, w, r1, r2, r3, rhs)
+    assert int((status != 0).sum()) == 0
+    sol = sol.clone()
+    prod = kkt.add_Kx_to_y(model, w, r1, r2, r3, sol)
+    res = (prod - rhs).norm(dim=1) / rhs.norm(dim=1)
+    assert float(res.max()) < 1e-9
+    # linearity: solve(a b1 + b2) == a solve(b1) + solve(b2) on the same factorization
+    kkt.factor(model, w, r1, r2, r3)
+    b2 = torch.roll(rhs, 1, dims=0)
+    s1 = kkt.solve(model, rhs).clone()
+    s2 = kkt.solve(model, b2).clone()
+    s12 = kkt.solve(model, (0.5 * rhs + b2).contiguous())
+    scale = (0.5 * s1 + s2).abs().amax(dim=1, keepdim=True)
+    assert float(((s12 - (0.5 * s1 + s2)).abs() / scale).max()) < 1e-9
+    # idempotence of the fused step
+    sol_again, _ = kkt.factor_solve(model, w, r1, r2, r3, rhs)
+    assert torch.equal(sol_again, sol)
+    # sampled oracle check
+    od = rk.newton_kkt_dims(n, m, T)
+    pick = [0, 1234, batch - 1]
+    ref, st = KKTOracle(od).batch(*[a[pick].cpu().numpy() for a in (model, w, r1, r2, r3, rhs)])
+    assert st.tolist() == [0, 0, 0]
+    got = sol[pick].cpu().numpy()
+    assert (np.abs(got - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= REL
