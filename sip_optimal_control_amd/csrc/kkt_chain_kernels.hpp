@@ -303,5 +303,128 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
   }
 }
 
+// y += K x (helpers.cpp:953-1368) for a uniform chain.  The workgroup of stage i owns the state
+// and control rows of stage i, the dynamics rows of node i + 1 (plus the root's at i = 0) and the
+// constraint rows of node i and edge i: everything they touch is in stage i's model item (staged
+// in LDS) and in a few slices of x.  Vectors are [x | theta (th entries) | y | z].
+__global__ void __launch_bounds__(TPB)
+apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ model_all,
+                   const double *__restrict__ w_all, const double *__restrict__ r1_all,
+                   const double *__restrict__ r2_all, const double *__restrict__ r3_all,
+                   const double *__restrict__ x_all, double *__restrict__ y_all, long batch) {
+  extern __shared__ double sm[];
+  const int n = ck.n, m = ck.m, T = ck.T;
+  const long p = blockIdx.x / (T + 1);
+  const int i = blockIdx.x - (unsigned)(p * (T + 1));
+  if (p >= batch)
+    return;
+  const int tid = threadIdx.x;
+  const bool last = i == T;
+  const int c = last ? ck.cT : ck.cn, g = last ? ck.gT : ck.gn;
+  const int ce = last ? 0 : ck.ce, ge = last ? 0 : ck.ge;
+  const int nn = n * n, nm = n * m;
+  const int node_len = nn + (c + g) * n, edge_len = last ? 0 : ck.edge_len;
+  const int xt = ck.x_dim + th;
+  const long full = (long)xt + ck.y_dim + ck.z_dim;
+  const double *item = model_all + p * ck.model_len + (long)i * (ck.node_len + ck.edge_len);
+  const int x_s = i * (n + m), x_u = x_s + n;
+  const int y_dyn = i * (n + ck.cn), y_nc = y_dyn + n, y_next = y_dyn + n + ck.cn;
+  const int y_ec = T * (n + ck.cn) + n + ck.cT + i * ck.ce;
+  const int z_n = i * ck.gn, z_e = T * ck.gn + ck.gT + i * ck.ge;
+  const double *w = w_all + p * ck.z_dim, *r1 = r1_all + p * xt, *r2 = r2_all + p * ck.y_dim;
+  const double *r3 = r3_all + p * ck.z_dim;
+  const double *x_x = x_all + p * full, *x_y = x_x + xt, *x_z = x_y + ck.y_dim;
+  double *y_x = y_all + p * full, *y_y = y_x + xt, *y_z = y_y + ck.y_dim;
+
+  double *buf = sm, *v = buf + ck.lds_item;
+  // vector slices in LDS: x_i | u_i | ydyn_i | ydyn_{i+1} | yc_node | z_node | yc_edge | z_edge
+  double *vx = v, *vu = vx + n, *vd = vu + m, *vdn = vd + n, *vyc = vdn + n, *vzn = vyc + c, *vye = vzn + g,
+         *vze = vye + ce;
+  stage_copy2(buf, item, node_len + edge_len, tid);
+  for (int k = tid; k < n; k += TPB) {
+    vx[k] = x_x[x_s + k];
+    vd[k] = x_y[y_dyn + k];
+    if (!last)
+      vdn[k] = x_y[y_next + k];
+  }
+  if (!last)
+    for (int k = tid; k < m; k += TPB)
+      vu[k] = x_x[x_u + k];
+  for (int k = tid; k < c; k += TPB)
+    vyc[k] = x_y[y_nc + k];
+  for (int k = tid; k < g; k += TPB)
+    vzn[k] = x_z[z_n + k];
+  for (int k = tid; k < ce; k += TPB)
+    vye[k] = x_y[y_ec + k];
+  for (int k = tid; k < ge; k += TPB)
+    vze[k] = x_z[z_e + k];
+  __syncthreads();
+  const double *Q = buf, *Jc = buf + nn, *Jg = Jc + c * n, *eb = buf + node_len;
+  const double *eQ = eb, *M = eb + nn, *R = M + nm, *A = R + m * m, *B = A + nn, *Jxc = B + nm, *Juc = Jxc + ce * n,
+               *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
+  auto dotr = [](const double *Mx, int ld, int row, int cols, const double *vec) { // row of a column-major block
+    double acc = 0.0;
+    for (int col = 0; col < cols; ++col)
+      acc += Mx[row + ld * col] * vec[col];
+    return acc;
+  };
+  auto dotc = [](const double *Mx, int ld, int col, int rows, const double *vec) { // column
+    const double *a = Mx + ld * col;
+    double acc = 0.0;
+    for (int r = 0; r < rows; ++r)
+      acc += a[r] * vec[r];
+    return acc;
+  };
+  const int n_rows = n + (last ? 0 : m + n) + c + g + ce + ge + (i == 0 ? n : 0);
+  for (int r = tid; r < n_rows; r += TPB) {
+    int q = r;
+    if (q < n) { // state rows: H x + C^T y + G^T z + r1 x
+      double acc = dotr(Q, n, q, n, vx) + dotc(Jc, c, q, c, vyc) + dotc(Jg, g, q, g, vzn) - vd[q];
+      if (!last)
+        acc += dotr(eQ, n, q, n, vx) + dotr(M, n, q, m, vu) + dotc(A, n, q, n, vdn) + dotc(Jxc, ce, q, ce, vye) +
+               dotc(Jxg, ge, q, ge, vze);
+      y_x[x_s + q] += acc + r1[x_s + q] * vx[q];
+      continue;
+    }
+    q -= n;
+    if (!last) {
+      if (q < m) { // control rows
+        const double acc = dotc(M, n, q, n, vx) + dotr(R, m, q, m, vu) + dotc(B, n, q, n, vdn) +
+                           dotc(Juc, ce, q, ce, vye) + dotc(Jug, ge, q, ge, vze);
+        y_x[x_u + q] += acc + r1[x_u + q] * vu[q];
+        continue;
+      }
+      q -= m;
+      if (q < n) { // dynamics rows of node i + 1: A x + B u - x_{i+1} - r2 y
+        const double acc = dotr(A, n, q, n, vx) + dotr(B, n, q, m, vu) - x_x[x_s + n + m + q];
+        y_y[y_next + q] += acc - r2[y_next + q] * vdn[q];
+        continue;
+      }
+      q -= n;
+    }
+    if (q < c) {
+      y_y[y_nc + q] += dotr(Jc, c, q, n, vx) - r2[y_nc + q] * vyc[q];
+      continue;
+    }
+    q -= c;
+    if (q < g) {
+      y_z[z_n + q] += dotr(Jg, g, q, n, vx) - (w[z_n + q] + r3[z_n + q]) * vzn[q];
+      continue;
+    }
+    q -= g;
+    if (q < ce) {
+      y_y[y_ec + q] += dotr(Jxc, ce, q, n, vx) + dotr(Juc, ce, q, m, vu) - r2[y_ec + q] * vye[q];
+      continue;
+    }
+    q -= ce;
+    if (q < ge) {
+      y_z[z_e + q] += dotr(Jxg, ge, q, n, vx) + dotr(Jug, ge, q, m, vu) - (w[z_e + q] + r3[z_e + q]) * vze[q];
+      continue;
+    }
+    q -= ge; // i == 0: the root's dynamics rows, -x_root - r2 y (helpers.cpp:1081-1085)
+    y_y[y_dyn + q] += -vx[q] - r2[y_dyn + q] * vd[q];
+  }
+}
+
 } // namespace kkt
 } // namespace sipamd

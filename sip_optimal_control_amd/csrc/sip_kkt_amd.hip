@@ -37,7 +37,7 @@ struct sip_kkt_plan {
   sipamd::kkt::Meta meta{};
   bool chain_kernels = false; // uniform chain: arithmetic-offset kernels (kkt_chain_kernels.hpp)
   sipamd::kkt::ChainKkt ck{};
-  size_t lds_chain_condense = 0, lds_chain_recover = 0;
+  size_t lds_chain_condense = 0, lds_chain_recover = 0, lds_chain_apply = 0;
   // theta (sip_kkt_plan_set_theta)
   int theta_dim = 0;
   std::vector<long> toff[sipamd::kkt::TH_NUM_BLOCKS];
@@ -395,6 +395,7 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
     ck.lds_rows = even(cgn + cge);                // condense: weights | weighted rhs rows
     p->lds_chain_condense = sizeof(double) * ((size_t)ck.lds_item + 2 * (size_t)ck.lds_rows);
     p->lds_chain_recover = sizeof(double) * ((size_t)ck.lds_tail + n + mm);
+    p->lds_chain_apply = sizeof(double) * ((size_t)ck.lds_item + 3 * n + mm + (size_t)ck.lds_rows);
     p->chain_kernels = p->lds_chain_condense <= 48 * 1024 &&
                        !(variant && std::strcmp(variant, "tables") == 0);
   }
@@ -581,8 +582,13 @@ int sip_kkt_add_Kx_to_y(const sip_kkt_plan *p, const double *d_model, const doub
   if ((!d_model && p->model_len > 0) || (!d_w && p->z_dim > 0) || (!d_r1 && p->x_dim > 0) ||
       (!d_r2 && p->y_dim > 0) || (!d_r3 && p->z_dim > 0) || !d_x || !d_y)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, (hipStream_t)stream,
-                     p->meta, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
+  if (p->chain_kernels)
+    hipLaunchKernelGGL(sipamd::kkt::apply_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_apply, (hipStream_t)stream, p->ck, 0, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y,
+                       (long)p->batch);
+  else
+    hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0,
+                       (hipStream_t)stream, p->meta, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
   return report(hipGetLastError(), "sip_kkt_add_Kx_to_y");
 }
 
@@ -736,10 +742,16 @@ int sip_kkt_add_Kx_to_y_theta(const sip_kkt_plan *p, const double *d_model, cons
   if (p == nullptr || p->theta_dim < 1 || !d_theta || !d_r1 || !d_x || !d_y)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
-  sipamd::kkt::Meta wide = p->meta; // the stagewise operator on [x | theta | y | z] vectors
-  wide.theta_dim = p->theta_dim;
-  hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, wide, d_model, d_w,
-                     d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
+  if (p->chain_kernels) {
+    hipLaunchKernelGGL(sipamd::kkt::apply_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_apply, s, p->ck, p->theta_dim, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y,
+                       (long)p->batch);
+  } else {
+    sipamd::kkt::Meta wide = p->meta; // the stagewise operator on [x | theta | y | z] vectors
+    wide.theta_dim = p->theta_dim;
+    hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, wide, d_model,
+                       d_w, d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
+  }
   hipLaunchKernelGGL(sipamd::kkt::apply_theta_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB), 0, s, p->meta,
                      p->theta_meta, d_theta, d_r1, d_x, d_y, (long)p->batch);
   return report(hipGetLastError(), "sip_kkt_add_Kx_to_y_theta");
