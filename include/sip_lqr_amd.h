@@ -135,9 +135,12 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
 
 /* Replaces: LQR::factor_with_status() alone (lqr.cpp:645-731; called by
  * CallbackProvider::factor, helpers.cpp:368).  Leaves the factor state in
- * d_workspace and the K part of d_gains for later sip_lqr_solve() calls.  The
- * split entry points run on the general engine for every shape; its factor
- * state is not interchangeable with the fused launch's spill. */
+ * d_workspace and the K part of d_gains for later sip_lqr_solve() calls.  For
+ * shapes with a fused kernel both split entry points re-run the fused sweep
+ * (factor: on a zero right-hand side; solve: with the given one -- refactoring
+ * is an order of magnitude cheaper than a second, slower kernel family); other
+ * shapes run on the general engine, whose work arena holds the reference's
+ * factor state.  sol of a problem whose status != SUCCESS is unspecified. */
 int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
                    int32_t *d_status, void *d_workspace, void *stream);
 

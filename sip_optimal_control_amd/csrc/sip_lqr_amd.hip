@@ -32,6 +32,10 @@ struct sip_lqr_plan {
   // laid out at plan creation (host only), uploaded at first use.
   mutable sipamd::GenericPlan gen;
   mutable bool gen_uploaded = false;
+  // Split factor / solve of a shape with a fused kernel: both re-run the fused sweep (factor on a
+  // zero right-hand side), which beats a second, slower kernel family by an order of magnitude;
+  // SIP_LQR_SPLIT=general keeps them on the general engine.
+  bool split_on_fused = false;
 };
 
 #ifdef SIP_LQR_STAMPS
@@ -158,6 +162,23 @@ int32_t *generic_status(const sip_lqr_plan *p, void *ws) {
   return (int32_t *)((char *)ws + (body + 15) / 16 * 16);
 }
 
+// Workspace of the fused kernel: spill | scratch vecs (zero rhs of factor) | scratch sol |
+// status copy (for sip_lqr_solve, which has no status argument).
+struct FusedSplit {
+  size_t vecs, sol, status, total;
+};
+FusedSplit fused_split_layout(const sip_lqr_plan *p) {
+  const size_t spill = (size_t)p->batch * ((size_t)p->T + 1) * (size_t)p->ws_slot * scalar_size(p);
+  const size_t vb = (size_t)p->batch * ((size_t)(p->T + 1) * 2 * p->n + (size_t)p->T * p->m) * scalar_size(p);
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  FusedSplit f;
+  f.vecs = up(spill);
+  f.sol = f.vecs + (p->split_on_fused ? up(vb) : 0);
+  f.status = f.sol + (p->split_on_fused ? up(vb) : 0);
+  f.total = f.status + (p->split_on_fused ? up((size_t)p->batch * sizeof(int32_t)) : 0);
+  return f;
+}
+
 int report(hipError_t e, const char *what) {
   if (e == hipSuccess)
     return SIP_LQR_OK;
@@ -195,6 +216,8 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
                                                        : "tree_generic(chain layout)/f64");
   p->ws_slot = k ? k->ws_slot : 0;
   p->launch_fs = k ? k->launch_fs : nullptr;
+  const char *split = std::getenv("SIP_LQR_SPLIT");
+  p->split_on_fused = p->launch_fs != nullptr && !(split && std::strcmp(split, "general") == 0);
   init_generic(p);
   *plan = p;
   return SIP_LQR_OK;
@@ -230,10 +253,9 @@ size_t sip_lqr_status_bytes(const sip_lqr_plan *p) {
   return (size_t)p->batch * sizeof(int32_t);
 }
 size_t sip_lqr_workspace_bytes(const sip_lqr_plan *p) {
-  // one buffer serves the fused kernel and the general engine (never both at
-  // once): the larger of the two
-  const size_t fused = (size_t)p->batch * ((size_t)p->T + 1) * (size_t)p->ws_slot * scalar_size(p);
-  return std::max(fused, generic_ws_bytes(p));
+  // one buffer serves the fused kernel (+ the scratch of its split entry points) and the
+  // general engine (never both at once): the larger of the two
+  return std::max(fused_split_layout(p).total, generic_ws_bytes(p));
 }
 
 } // extern "C"
@@ -377,6 +399,16 @@ int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
   if (plan == nullptr || !d_mats || !d_status || !d_workspace || (plan->T > 0 && !d_gains))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
+  if (plan->split_on_fused) { // fused sweep on a zero right-hand side: K, statuses
+    const FusedSplit f = fused_split_layout(plan);
+    char *w = (char *)d_workspace;
+    hipError_t e = hipMemsetAsync(w + f.vecs, 0, f.sol - f.vecs, s);
+    if (e == hipSuccess)
+      e = plan->launch_fs(plan, d_mats, w + f.vecs, w + f.sol, d_gains, d_status, d_workspace, s);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(w + f.status, d_status, (size_t)plan->batch * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    return report(e, "sip_lqr_factor(fused)");
+  }
   hipError_t e = ensure_generic(plan);
   if (e == hipSuccess)
     e = plan->dtype == SIP_LQR_F32
@@ -393,6 +425,12 @@ int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats, const void *d_ve
   if (plan == nullptr || !d_mats || !d_vecs || !d_sol || !d_workspace || (plan->T > 0 && !d_gains))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
+  if (plan->split_on_fused) { // the fused sweep again, now with the right-hand side
+    const FusedSplit f = fused_split_layout(plan);
+    return report(plan->launch_fs(plan, d_mats, d_vecs, d_sol, d_gains,
+                                  (int32_t *)((char *)d_workspace + f.status), d_workspace, s),
+                  "sip_lqr_solve(fused)");
+  }
   hipError_t e = ensure_generic(plan);
   const int32_t *st = generic_status(plan, d_workspace);
   if (e == hipSuccess)

@@ -63,10 +63,13 @@ def test_forced_general_engine_equals_fused_kernel(oracle_lib):
     assert _rel(g1.cpu().numpy(), g2.cpu().numpy()) <= 1e-9
 
 
-def test_split_factor_then_repeated_solve(oracle_lib):
+@pytest.mark.parametrize("split", ["", "general"])
+def test_split_factor_then_repeated_solve(oracle_lib, monkeypatch, split):
     """sip_lqr_factor once, sip_lqr_solve twice with different right-hand sides
-    (tests/lqr_test.cpp:431-450; CallbackProvider::factor / ::solve)."""
+    (tests/lqr_test.cpp:431-450; CallbackProvider::factor / ::solve): on the fused kernel
+    (default for shapes that have one) and on the general engine (SIP_LQR_SPLIT=general)."""
     from sip_optimal_control_amd import BatchedChainLQR
+    monkeypatch.setenv("SIP_LQR_SPLIT", split)
     n, m, T, batch = 12, 4, 20, 6
     mats, vecs = _make(n, m, T, batch, seed=77)
     _, vecs2 = _make(n, m, T, batch, seed=78)
@@ -83,8 +86,10 @@ def test_split_factor_then_repeated_solve(oracle_lib):
         assert _rel(g.cpu().numpy(), ref_gains) <= 1e-9
 
 
-def test_split_solve_skips_failed_problems(oracle_lib):
+@pytest.mark.parametrize("split", ["", "general"])
+def test_split_solve_skips_failed_problems(oracle_lib, monkeypatch, split):
     from sip_optimal_control_amd import BatchedChainLQR, ChainShape
+    monkeypatch.setenv("SIP_LQR_SPLIT", split)
     n, m, T, batch = 4, 2, 5, 4
     shape = ChainShape(n, m, T)
     mats, vecs = _make(n, m, T, batch, seed=3)
@@ -102,7 +107,8 @@ def test_split_solve_skips_failed_problems(oracle_lib):
     ref_sol, _, ref_status = oracle_lib.chain_batch(n, m, T, bad.cpu().numpy(), vecs.cpu().numpy())
     np.testing.assert_array_equal(st, ref_status)
     out = sol.cpu().numpy()
-    assert (out[1] == -7.0).all() and (out[2] == -7.0).all()       # untouched, like the oracle
+    if split == "general":  # the general engine leaves failed problems untouched, like the oracle;
+        assert (out[1] == -7.0).all() and (out[2] == -7.0).all()   # the fused sweep leaves them unspecified
     assert _rel(out[[0, 3]], ref_sol[[0, 3]]) <= 1e-9
     # the fused launch reports the same statuses
     _, _, st2 = solver.factor_solve(bad, vecs)
