@@ -140,3 +140,32 @@ def five_node_variable_tree_eigen():
     for e, m in enumerate(prob["control_dims"]):
         b["r"][e] = _eigen_linspaced(m, -0.2 + 0.04 * e, 0.1 + 0.03 * e)
     return prob
+
+
+def variable_benchmark_problem(shape, T, base_n, base_m, rng):
+    """VariableLQRProblem of the reference's benchmark (benchmarks/lqr_benchmark.cpp:209-310):
+    shape 0 heterogeneous chain, 1 shallow wide tree (every edge leaves the root), 2 binary tree;
+    state_dims[node] = max(1, base_n + node % 3 - 1), control_dims[edge] = max(1, base_m + edge % 3 - 1);
+    A = 0.05 N(0,1), B = 0.1 N(0,1), M = 0, R = G^T G + I, Q = S^T S + 1e-3 I, q, r, c ~ N(0,1),
+    delta = 1e-3 + 0.1 U(0,1) (the value generator is numpy's: std::normal_distribution is
+    implementation-defined)."""
+    sd = [max(1, base_n + (node % 3) - 1) for node in range(T + 1)]
+    cd = [max(1, base_m + (edge % 3) - 1) for edge in range(T)]
+    children = list(range(1, T + 1))
+    parents = [{0: e, 1: 0, 2: (e + 1 - 1) // 2}[shape] for e in range(T)]
+    blocks = {k: [] for k in ("Q", "M", "R", "q", "r", "A", "B", "c", "delta")}
+    for n in sd:
+        S = rng.normal(size=(n, n))
+        blocks["Q"].append(S.T @ S + 1e-3 * np.eye(n))
+        blocks["q"].append(rng.normal(size=n))
+        blocks["c"].append(rng.normal(size=n))
+        blocks["delta"].append(1e-3 + 0.1 * rng.random(n))
+    for e, m in enumerate(cd):
+        np_, nc = sd[parents[e]], sd[children[e]]
+        G = rng.normal(size=(m, m))
+        blocks["A"].append(0.05 * rng.normal(size=(nc, np_)))
+        blocks["B"].append(0.1 * rng.normal(size=(nc, m)))
+        blocks["M"].append(np.zeros((np_, m)))
+        blocks["R"].append(G.T @ G + np.eye(m))
+        blocks["r"].append(rng.normal(size=m))
+    return _problem(parents, children, sd, cd, blocks)

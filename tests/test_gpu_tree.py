@@ -155,3 +155,29 @@ def test_random_tree_batch_matches_oracle(oracle_lib):
         x, u, y = s.unpack_solution(b)
         for a, bb in list(zip(x, xo)) + list(zip(u, uo)) + list(zip(y, yo)):
             np.testing.assert_allclose(a, bb, rtol=0, atol=1e-11 * max(1.0, np.abs(bb).max()))
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])
+@pytest.mark.parametrize("T,base_n", [(31, 4), (31, 8), (63, 4)])
+def test_reference_variable_benchmark_shapes(oracle_lib, shape, T, base_n):
+    """The shapes of BM_LQRVariableFactorSolve (benchmarks/lqr_benchmark.cpp:209-310, 547-555):
+    heterogeneous chain, shallow wide tree, binary tree with per-node dimensions."""
+    rng = np.random.default_rng(17 + 31 * shape)
+    batch = 3
+    probs = [rp.variable_benchmark_problem(shape, T, base_n, 2, rng) for _ in range(batch)]
+    s = _solver(probs[0], batch=batch)
+    s.pack([p["blocks"] for p in probs])
+    st = s.factor()
+    s.solve()
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [0] * batch
+    for b, prob in enumerate(probs):
+        lqr = oracle_lib.TreeLQR(prob["parents"], prob["children"], prob["state_dims"], prob["control_dims"],
+                                 prob["blocks"])
+        assert lqr.factor() == 0
+        xo, uo, yo = lqr.solve()
+        x, u, y = s.unpack_solution(b)
+        for a, bb in list(zip(x, xo)) + list(zip(u, uo)) + list(zip(y, yo)):
+            np.testing.assert_allclose(a, bb, rtol=0, atol=1e-10 * max(1.0, np.abs(bb).max()))
+        assert dense_kkt.residual_norm(prob["parents"], prob["children"], prob["state_dims"], prob["control_dims"],
+                                       prob["blocks"], x, u, y) < 1e-9

@@ -21,6 +21,51 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _time(fn, steps, warmup=2):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def theta_main(args):
+    import numpy as np
+    import torch
+    from sip_optimal_control_amd import BatchedNewtonKKT
+    from oracle.kkt import KKTDims, KKTOracle
+    from tests import reference_kkt_problems as rk
+    n, m, T, batch, p = args.n, args.m, args.T, args.batch, args.theta
+    base = rk.newton_kkt_dims(n, m, T)
+    dims = KKTDims(base.parents, base.children, base.sd, base.cd, base.ncd, base.ngd, base.ecd, base.egd, theta_dim=p)
+    few = 8  # distinct problems (host generator), tiled over the batch
+    model, w, r1, r2, r3, rhs, theta_model = rk.newton_kkt_problem(dims, seed=0, batch=few, r2_max=1e2)
+    tile = lambda a: torch.from_numpy(np.ascontiguousarray(np.tile(a, (batch // few, 1)))).cuda()
+    d = [tile(a) for a in (model, theta_model, w, r1, r2, r3, rhs)]
+    kkt = BatchedNewtonKKT(dims.parents, dims.children, dims.sd, dims.cd, dims.ncd, dims.ngd, dims.ecd, dims.egd,
+                           batch=batch, theta_dim=p)
+    sol = torch.zeros(batch, dims.full_dim, dtype=torch.float64, device="cuda")
+    ms_factor = _time(lambda: kkt.factor_theta(*d[:6]), args.steps)
+    assert int((kkt.status != 0).sum()) == 0
+    ms_solve = _time(lambda: kkt.solve_theta(d[0], d[1], d[6], sol=sol), args.steps)
+    ms_split0 = _time(lambda: kkt.factor(d[0], d[2], d[3][:, :dims.x_dim].contiguous(), d[4], d[5]), args.steps)
+    o = KKTOracle(dims)
+    assert o.factor_theta(model[0], theta_model[0], w[0], r1[0], r2[0], r3[0]) == 0
+    ref = o.solve_theta(model[0], theta_model[0], rhs[0])
+    err = float(np.abs(sol[0].cpu().numpy() - ref).max() / np.abs(ref).max())
+    print(json.dumps({"metric": "newton_kkt_theta_factor_and_solve_ms", "theta_dim": p, "batch": batch,
+                      "config": f"NewtonKKTProblem(n={n}, m={m}, T={T}, p={p})", "riccati": kkt.kernel_name,
+                      "ms_factor_theta": ms_factor, "ms_solve_theta": ms_solve, "ms_factor_stagewise": ms_split0,
+                      "factor_theta_per_sec": batch / (ms_factor * 1e-3), "solve_theta_per_sec": batch / (ms_solve * 1e-3),
+                      "max_rel_err_vs_oracle": err}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=12)
@@ -30,7 +75,12 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--theta", type=int, default=0,
+                    help="theta_dim p > 0: time the split factor_theta / solve_theta path instead "
+                         "(NewtonKKTProblem(n, m, T, p), newton_kkt_benchmark.cpp:388-449)")
     args = ap.parse_args()
+    if args.theta > 0:
+        return theta_main(args)
     import numpy as np
     import torch
     from sip_optimal_control_amd import BatchedNewtonKKT, synthetic
