@@ -10,7 +10,11 @@
 #include <cstdint>
 #include <vector>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "tree_generic.hpp"
+#include "tree_lds.hpp"
 
 namespace sipamd {
 
@@ -178,19 +182,39 @@ struct GenericPlan {
     return hipSuccess;
   }
 
+  // LDS-resident kernels (tree_lds.hpp) when the largest node fits in 64 KB; SIP_LQR_TREE=global
+  // keeps the global-memory kernels (tests, A/B).
+  template <class S>
+  size_t lds_bytes() const {
+    const char *v = std::getenv("SIP_LQR_TREE");
+    if (v != nullptr && std::strcmp(v, "global") == 0)
+      return 0;
+    const size_t need = (size_t)tree::lds_scalars(max_n, max_m) * sizeof(S);
+    return need <= 64 * 1024 ? need : 0;
+  }
+
   template <class S>
   hipError_t launch_factor(long batch, const void *in0, void *ws, void *gain, int32_t *status,
                            hipStream_t stream) const {
-    hipLaunchKernelGGL((tree::factor_kernel<S>), dim3((unsigned)batch), dim3(tree::TPB), 0, stream, meta,
-                       (const S *)in0, (S *)ws, (S *)gain, (int *)status, batch);
+    if (const size_t lds = lds_bytes<S>())
+      hipLaunchKernelGGL((tree::factor_kernel_lds<S>), dim3((unsigned)batch), dim3(tree::TPB), lds, stream, meta,
+                         (const S *)in0, (S *)ws, (S *)gain, (int *)status, batch);
+    else
+      hipLaunchKernelGGL((tree::factor_kernel<S>), dim3((unsigned)batch), dim3(tree::TPB), 0, stream, meta,
+                         (const S *)in0, (S *)ws, (S *)gain, (int *)status, batch);
     return hipGetLastError();
   }
   template <class S>
   hipError_t launch_solve(long batch, const void *in0, const void *in1, void *ws, void *gain, void *out,
                           const int32_t *status, hipStream_t stream) const {
-    hipLaunchKernelGGL((tree::solve_kernel<S>), dim3((unsigned)batch), dim3(tree::TPB), 0, stream, meta,
-                       (const S *)in0, (const S *)in1, (S *)ws, (S *)gain, (S *)out, (const int *)status,
-                       batch);
+    if (const size_t lds = lds_bytes<S>())
+      hipLaunchKernelGGL((tree::solve_kernel_lds<S>), dim3((unsigned)batch), dim3(tree::TPB), lds, stream, meta,
+                         (const S *)in0, (const S *)in1, (S *)ws, (S *)gain, (S *)out, (const int *)status,
+                         batch);
+    else
+      hipLaunchKernelGGL((tree::solve_kernel<S>), dim3((unsigned)batch), dim3(tree::TPB), 0, stream, meta,
+                         (const S *)in0, (const S *)in1, (S *)ws, (S *)gain, (S *)out, (const int *)status,
+                         batch);
     return hipGetLastError();
   }
 };
