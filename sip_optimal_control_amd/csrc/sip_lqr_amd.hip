@@ -110,6 +110,13 @@ const KernelEntry kKernels[] = {
     MF32(8), QW16_STAGED(12, 4), QW16_STAGED(4, 2), QW16_DIRECT(12, 4),
     QW16_DIRECT(4, 2),  QW16_DIRECT(1, 1), QW16_DIRECT(2, 1),
     QW16_DIRECT(3, 2),  QW16_DIRECT(8, 3),
+    // the grid of the reference's benchmarks (lqr_benchmark.cpp:537-545,
+    // newton_kkt_benchmark.cpp:264-273: n in {4, 6, 8}, m in {1, 2, 3, 4}; n = 16 has no
+    // vector lane left and runs on the general engine) and n = 12 with fewer controls
+    QW16_STAGED(4, 4),  QW16_STAGED(6, 2),  QW16_STAGED(6, 4),  QW16_STAGED(8, 2),
+    QW16_STAGED(8, 4),  QW16_STAGED(12, 2), QW16_DIRECT(4, 1),  QW16_DIRECT(4, 3),
+    QW16_DIRECT(6, 1),  QW16_DIRECT(6, 3),  QW16_DIRECT(8, 1),  QW16_DIRECT(12, 1),
+    QW16_DIRECT(12, 3),
 };
 
 const KernelEntry *find_kernel(int dtype, int n, int m) {

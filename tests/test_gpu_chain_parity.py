@@ -45,6 +45,21 @@ def test_factor_solve_matches_oracle(oracle_lib, n, m, T, batch):
         assert _rel(gains, ref_gains) <= TOL
 
 
+@pytest.mark.parametrize("n", [4, 6, 8, 12])
+@pytest.mark.parametrize("m", [1, 2, 3, 4])
+def test_reference_benchmark_grid_has_fused_kernels(oracle_lib, n, m):
+    """The (state_dim, control_dim) grid of the reference's benchmarks (lqr_benchmark.cpp:537-545,
+    newton_kkt_benchmark.cpp:264-273; n = 16 runs on the general engine) on dedicated kernels."""
+    from sip_optimal_control_amd import BatchedChainLQR
+    T, batch = 16, 13
+    assert "qw16" in BatchedChainLQR(n, m, T, batch, device="cuda:0").kernel_name
+    shape, mats, vecs, sol, gains, status = _run(n, m, T, batch, seed=1000 + 10 * n + m)
+    ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats, vecs)
+    np.testing.assert_array_equal(status, ref_status)
+    assert (ref_status == 0).all()
+    assert _rel(sol, ref_sol) <= TOL and _rel(gains, ref_gains) <= TOL
+
+
 def test_kkt_residual_full_size(oracle_lib):
     """BASELINE C2 shape at full batch: KKT residual of every GPU solution."""
     from oracle import dense_kkt
