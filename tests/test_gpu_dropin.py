@@ -20,3 +20,17 @@ def test_cpp_dropin_suite():
     assert proc.returncode == 0, proc.stdout[-3000:]
     assert "0 failures" in proc.stdout
     assert proc.stdout.count("[  OK  ]") >= 17
+
+
+def test_cpp_callback_provider_suite():
+    """tests/variable_dimensions_test.cpp's CallbackProvider tests (chain, sibling edges,
+    zero-dimensional root, Schur variables) against the drop-in CallbackProvider class."""
+    import __graft_entry__ as entry
+    entry.build_hip()
+    exe = entry.build_callback_provider_test()
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(proc.stdout)
+    print(proc.stderr)
+    assert proc.returncode == 0, proc.stdout[-3000:]
+    assert "0 failures" in proc.stdout
+    assert proc.stdout.count("[  OK  ]") == 5
