@@ -213,6 +213,9 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes * batch,
+                # rate of the bytes the kernel really moves (PMC traffic / live launch time);
+                # MI355X_MICROARCH.md: a float4 copy sustains ~6.3 TB/s on this part
+                "traffic_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
             },
         }
         if dt == "f32":
