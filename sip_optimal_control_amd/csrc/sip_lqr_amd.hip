@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -36,6 +37,13 @@ struct sip_lqr_plan {
   // zero right-hand side), which beats a second, slower kernel family by an order of magnitude;
   // SIP_LQR_SPLIT=general keeps them on the general engine.
   bool split_on_fused = false;
+  // Uniform shapes without an exact kernel run on the next larger fused kernel (kn >= n, km >= m):
+  // the problem is embedded in a kn x km one whose extra states / controls decouple exactly
+  // (Q = I, R = I, delta = 1 on their diagonal, zeros elsewhere: x = y = u = 0 there), by a
+  // device-side repack before and after the sweep.  SIP_LQR_PAD=0 keeps the general engine.
+  bool padded = false;
+  int kn = 0, km = 0;
+  std::string name_storage;
 };
 
 #ifdef SIP_LQR_STAMPS
@@ -128,6 +136,26 @@ const KernelEntry *find_kernel(int dtype, int n, int m) {
   return nullptr;
 }
 
+// Smallest fused fp64 kernel that can embed an (n, m) chain: least N, then a staged kernel with
+// the least M, then a direct one.
+const KernelEntry *find_embedding_kernel(int n, int m) {
+  const KernelEntry *best = nullptr;
+  auto better = [&](const KernelEntry &k) {
+    if (best == nullptr)
+      return true;
+    if (k.n != best->n)
+      return k.n < best->n;
+    const bool ks = std::strstr(k.name, "staged") != nullptr, bs = std::strstr(best->name, "staged") != nullptr;
+    if (ks != bs)
+      return ks;
+    return k.m < best->m;
+  };
+  for (const auto &k : kKernels)
+    if (k.dtype == SIP_LQR_F64 && k.n >= n && k.m >= m && better(k))
+      best = &k;
+  return best;
+}
+
 size_t scalar_size(const sip_lqr_plan *p) {
   return p->dtype == SIP_LQR_F32 ? sizeof(float) : sizeof(double);
 }
@@ -169,21 +197,164 @@ int32_t *generic_status(const sip_lqr_plan *p, void *ws) {
   return (int32_t *)((char *)ws + (body + 15) / 16 * 16);
 }
 
+// ---- embedding of an (n, m) chain in a (N, M) one -----------------------------------------
+struct PadDims {
+  int n, m, N, M, T;
+  long mats_len, vecs_len, gains_len, pmats_len, pvecs_len, pgains_len;
+};
+PadDims pad_dims(const sip_lqr_plan *p) {
+  PadDims d;
+  d.n = p->n, d.m = p->m, d.N = p->kn, d.M = p->km, d.T = p->T;
+  const long n = d.n, m = d.m, N = d.N, M = d.M, T = d.T;
+  d.mats_len = (T + 1) * (n * n + n) + T * (n * n + 2 * n * m + m * m);
+  d.vecs_len = (T + 1) * 2 * n + T * m;
+  d.gains_len = T * (m * n + m);
+  d.pmats_len = (T + 1) * (N * N + N) + T * (N * N + 2 * N * M + M * M);
+  d.pvecs_len = (T + 1) * 2 * N + T * M;
+  d.pgains_len = T * (M * N + M);
+  return d;
+}
+
+// one thread per scalar of the padded mats of one problem
+__global__ void __launch_bounds__(256)
+pad_mats_kernel(const PadDims d, const double *__restrict__ mats, double *__restrict__ pm, long batch) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= batch * d.pmats_len)
+    return;
+  const long prob = idx / d.pmats_len;
+  long at = idx - prob * d.pmats_len;
+  const int n = d.n, m = d.m, N = d.N, M = d.M;
+  const int pstage = N * N + N + N * N + 2 * N * M + M * M, stage = n * n + n + n * n + 2 * n * m + m * m;
+  const int i = (int)(at / pstage);
+  at -= (long)i * pstage;
+  const double *src = mats + prob * d.mats_len + (long)i * stage;
+  double v;
+  int o = (int)at;
+  if (o < N * N) { // Q: identity on the extra diagonal
+    const int col = o / N, row = o - col * N;
+    v = (row < n && col < n) ? src[row + n * col] : (row == col ? 1.0 : 0.0);
+  } else if ((o -= N * N) < N) { // delta: 1 on the extra states
+    v = o < n ? src[n * n + o] : 1.0;
+  } else if ((o -= N) < N * N) { // A
+    const int col = o / N, row = o - col * N;
+    v = (row < n && col < n) ? src[n * n + n + row + n * col] : 0.0;
+  } else if ((o -= N * N) < N * M) { // B
+    const int col = o / N, row = o - col * N;
+    v = (row < n && col < m) ? src[2 * n * n + n + row + n * col] : 0.0;
+  } else if ((o -= N * M) < N * M) { // M (cross term)
+    const int col = o / N, row = o - col * N;
+    v = (row < n && col < m) ? src[2 * n * n + n + n * m + row + n * col] : 0.0;
+  } else { // R: identity on the extra diagonal
+    o -= N * M;
+    const int col = o / M, row = o - col * M;
+    v = (row < m && col < m) ? src[2 * n * n + n + 2 * n * m + row + m * col] : (row == col ? 1.0 : 0.0);
+  }
+  pm[idx] = v;
+}
+
+// vecs -> padded vecs (zeros on the extras); PAD = false: padded sol -> sol
+template <bool PAD>
+__global__ void __launch_bounds__(256)
+pad_vecs_kernel(const PadDims d, const double *__restrict__ src_all, double *__restrict__ dst_all, long batch) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long len = PAD ? d.pvecs_len : d.vecs_len;
+  if (idx >= batch * len)
+    return;
+  const long prob = idx / len;
+  long at = idx - prob * len;
+  const int n = d.n, m = d.m, N = d.N, M = d.M;
+  const int a = PAD ? N : n, b = PAD ? M : m;   // dims of the layout this thread indexes
+  const int oa = PAD ? n : N, ob = PAD ? m : M; // dims of the other layout
+  const int i = (int)(at / (2 * a + b));
+  const int o = (int)(at - (long)i * (2 * a + b));
+  int other = -1; // offset inside the other layout's stage, -1: an extra (padded) entry
+  if (o < a)
+    other = o < n ? o : -1;
+  else if (o < 2 * a)
+    other = (o - a) < n ? oa + (o - a) : -1;
+  else
+    other = (o - 2 * a) < m ? 2 * oa + (o - 2 * a) : -1;
+  const long other_at = prob * (PAD ? d.vecs_len : d.pvecs_len) + (long)i * (2 * oa + ob) + other;
+  dst_all[idx] = other >= 0 ? src_all[other_at] : 0.0;
+}
+
+// padded gains (K: M x N, k: M) -> gains (K: m x n, k: m)
+__global__ void __launch_bounds__(256)
+unpad_gains_kernel(const PadDims d, const double *__restrict__ pg, double *__restrict__ gains, long batch) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= batch * d.gains_len)
+    return;
+  const long prob = idx / d.gains_len;
+  long at = idx - prob * d.gains_len;
+  const int n = d.n, m = d.m, N = d.N, M = d.M;
+  const int i = (int)(at / (m * n + m));
+  const int o = (int)(at - (long)i * (m * n + m));
+  const double *src = pg + prob * d.pgains_len + (long)i * (M * N + M);
+  if (o < m * n) {
+    const int col = o / m, row = o - col * m;
+    gains[idx] = src[row + M * col];
+  } else {
+    gains[idx] = src[M * N + (o - m * n)];
+  }
+}
+
 // Workspace of the fused kernel: spill | scratch vecs (zero rhs of factor) | scratch sol |
 // status copy (for sip_lqr_solve, which has no status argument).
 struct FusedSplit {
-  size_t vecs, sol, status, total;
+  size_t vecs, sol, status, pmats, pgains, total;
 };
 FusedSplit fused_split_layout(const sip_lqr_plan *p) {
-  const size_t spill = (size_t)p->batch * ((size_t)p->T + 1) * (size_t)p->ws_slot * scalar_size(p);
-  const size_t vb = (size_t)p->batch * ((size_t)(p->T + 1) * 2 * p->n + (size_t)p->T * p->m) * scalar_size(p);
+  const size_t N = p->kn, M = p->km, T = p->T, B = (size_t)p->batch, sz = scalar_size(p);
+  const size_t spill = B * (T + 1) * (size_t)p->ws_slot * sz;
+  const size_t vb = B * ((T + 1) * 2 * N + T * M) * sz; // vecs / sol in the kernel's dimensions
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const bool scratch = p->split_on_fused || p->padded;
   FusedSplit f;
   f.vecs = up(spill);
-  f.sol = f.vecs + (p->split_on_fused ? up(vb) : 0);
-  f.status = f.sol + (p->split_on_fused ? up(vb) : 0);
-  f.total = f.status + (p->split_on_fused ? up((size_t)p->batch * sizeof(int32_t)) : 0);
+  f.sol = f.vecs + (scratch ? up(vb) : 0);
+  f.status = f.sol + (scratch ? up(vb) : 0);
+  f.pmats = f.status + (scratch ? up(B * sizeof(int32_t)) : 0);
+  f.pgains = f.pmats + (p->padded ? up(B * ((T + 1) * (N * N + N) + T * (N * N + 2 * N * M + M * M)) * sz) : 0);
+  f.total = f.pgains + (p->padded ? up(B * T * (M * N + M) * sz) : 0);
   return f;
+}
+
+// The fused sweep of a plan, through the embedding when the plan is padded.  vecs == nullptr: zero
+// right-hand side (split factor).  sol / gains == nullptr: not wanted.
+hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, void *sol, void *gains,
+                     int32_t *status, void *ws, hipStream_t s) {
+  const FusedSplit f = fused_split_layout(p);
+  char *w = (char *)ws;
+  hipError_t e = hipSuccess;
+  if (!p->padded) {
+    const void *v = vecs;
+    if (v == nullptr) {
+      e = hipMemsetAsync(w + f.vecs, 0, f.sol - f.vecs, s);
+      v = w + f.vecs;
+    }
+    if (e == hipSuccess)
+      e = p->launch_fs(p, mats, v, sol ? sol : (void *)(w + f.sol), gains, status, ws, s);
+    return e;
+  }
+  const PadDims d = pad_dims(p);
+  const long B = p->batch;
+  auto grid = [](long count) { return dim3((unsigned)((count + 255) / 256)); };
+  hipLaunchKernelGGL(pad_mats_kernel, grid(B * d.pmats_len), dim3(256), 0, s, d, (const double *)mats,
+                     (double *)(w + f.pmats), B);
+  if (vecs != nullptr)
+    hipLaunchKernelGGL(pad_vecs_kernel<true>, grid(B * d.pvecs_len), dim3(256), 0, s, d, (const double *)vecs,
+                       (double *)(w + f.vecs), B);
+  else
+    e = hipMemsetAsync(w + f.vecs, 0, f.sol - f.vecs, s);
+  if (e == hipSuccess)
+    e = p->launch_fs(p, w + f.pmats, w + f.vecs, w + f.sol, w + f.pgains, status, ws, s);
+  if (e == hipSuccess && sol != nullptr)
+    hipLaunchKernelGGL(pad_vecs_kernel<false>, grid(B * d.vecs_len), dim3(256), 0, s, d, (const double *)(w + f.sol),
+                       (double *)sol, B);
+  if (e == hipSuccess && gains != nullptr && d.gains_len > 0)
+    hipLaunchKernelGGL(unpad_gains_kernel, grid(B * d.gains_len), dim3(256), 0, s, d,
+                       (const double *)(w + f.pgains), (double *)gains, B);
+  return e == hipSuccess ? hipGetLastError() : e;
 }
 
 int report(hipError_t e, const char *what) {
@@ -219,8 +390,20 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
   p->n = n;
   p->m = m;
   p->device = device;
-  p->kernel_name = k ? k->name : (dtype == SIP_LQR_F32 ? "tree_generic(chain layout)/f32"
-                                                       : "tree_generic(chain layout)/f64");
+  p->kn = n, p->km = m;
+  const char *pad = std::getenv("SIP_LQR_PAD");
+  if (k == nullptr && !force_general && dtype == SIP_LQR_F64 && (want == nullptr || want[0] == 0) &&
+      !(pad && std::strcmp(pad, "0") == 0)) {
+    k = find_embedding_kernel(n, m);
+    if (k != nullptr) {
+      p->padded = true, p->kn = k->n, p->km = k->m;
+      p->name_storage = std::string(k->name) + " embedding (" + std::to_string(n) + "," + std::to_string(m) + ")";
+    }
+  }
+  p->kernel_name = p->padded ? p->name_storage.c_str()
+                   : k       ? k->name
+                             : (dtype == SIP_LQR_F32 ? "tree_generic(chain layout)/f32"
+                                                     : "tree_generic(chain layout)/f64");
   p->ws_slot = k ? k->ws_slot : 0;
   p->launch_fs = k ? k->launch_fs : nullptr;
   const char *split = std::getenv("SIP_LQR_SPLIT");
@@ -384,7 +567,7 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
   if (plan->launch_fs != nullptr)
-    return report(plan->launch_fs(plan, d_mats, d_vecs, d_sol, d_gains, d_status, d_workspace, s),
+    return report(run_fused(plan, d_mats, d_vecs, d_sol, d_gains, d_status, d_workspace, s),
                   "sip_lqr_factor_solve");
   // no dedicated kernel for this shape / dtype: general engine, two launches
   hipError_t e = ensure_generic(plan);
@@ -409,9 +592,7 @@ int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
   if (plan->split_on_fused) { // fused sweep on a zero right-hand side: K, statuses
     const FusedSplit f = fused_split_layout(plan);
     char *w = (char *)d_workspace;
-    hipError_t e = hipMemsetAsync(w + f.vecs, 0, f.sol - f.vecs, s);
-    if (e == hipSuccess)
-      e = plan->launch_fs(plan, d_mats, w + f.vecs, w + f.sol, d_gains, d_status, d_workspace, s);
+    hipError_t e = run_fused(plan, d_mats, nullptr, nullptr, d_gains, d_status, d_workspace, s);
     if (e == hipSuccess)
       e = hipMemcpyAsync(w + f.status, d_status, (size_t)plan->batch * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
     return report(e, "sip_lqr_factor(fused)");
@@ -434,8 +615,8 @@ int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats, const void *d_ve
   hipStream_t s = (hipStream_t)stream;
   if (plan->split_on_fused) { // the fused sweep again, now with the right-hand side
     const FusedSplit f = fused_split_layout(plan);
-    return report(plan->launch_fs(plan, d_mats, d_vecs, d_sol, d_gains,
-                                  (int32_t *)((char *)d_workspace + f.status), d_workspace, s),
+    return report(run_fused(plan, d_mats, d_vecs, d_sol, d_gains, (int32_t *)((char *)d_workspace + f.status),
+                            d_workspace, s),
                   "sip_lqr_solve(fused)");
   }
   hipError_t e = ensure_generic(plan);

@@ -30,18 +30,49 @@ def _make(n, m, T, batch, seed, dtype=None):
 
 
 @pytest.mark.parametrize("n,m,T,batch", [(16, 4, 16, 5), (5, 3, 7, 9), (7, 1, 4, 3), (15, 16, 3, 2)])
-def test_general_engine_fp64_matches_oracle(oracle_lib, n, m, T, batch):
+def test_general_engine_fp64_matches_oracle(oracle_lib, monkeypatch, n, m, T, batch):
     from sip_optimal_control_amd import BatchedChainLQR
+    monkeypatch.setenv("SIP_LQR_PAD", "0")  # no embedding in a larger fused kernel
     mats, vecs = _make(n, m, T, batch, seed=50 + n)
     solver = BatchedChainLQR(n, m, T, batch)
-    if (n, m) != (15, 16):
-        assert "tree_generic" in solver.kernel_name
+    assert "tree_generic" in solver.kernel_name
     sol, gains, status = solver.factor_solve(mats, vecs)
     torch.cuda.synchronize()
     ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats.cpu().numpy(), vecs.cpu().numpy())
     np.testing.assert_array_equal(status.cpu().numpy(), ref_status)
     assert _rel(sol.cpu().numpy(), ref_sol) <= 1e-9
     assert _rel(gains.cpu().numpy(), ref_gains) <= 1e-9
+
+
+@pytest.mark.parametrize("n,m,T,batch,host", [
+    (5, 3, 7, 9, "<6,4,staged>"), (7, 1, 4, 3, "<8,2,staged>"), (10, 3, 20, 13, "<12,4,staged>"),
+    (11, 4, 12, 5, "<12,4,staged>"), (9, 2, 9, 7, "<12,2,staged>"), (3, 1, 6, 4, "<3,2,direct>"),
+    (5, 3, 0, 2, "<6,4,staged>")])
+def test_embedding_in_the_next_fused_kernel(oracle_lib, n, m, T, batch, host):
+    """Uniform shapes without an exact kernel run on the next larger fused kernel: the extra states
+    and controls decouple exactly, so the real components match the oracle as usual.  Fused and
+    split entry points, one failing problem."""
+    from sip_optimal_control_amd import BatchedChainLQR, ChainShape
+    mats, vecs = _make(n, m, T, batch, seed=500 + 10 * n + m)
+    if T > 1 and batch > 2:
+        off = ChainShape(n, m, T).mats_off(1)["R"]
+        mats[2, off:off + m * m] = -torch.eye(m, dtype=torch.float64, device="cuda:0").reshape(-1)  # G failure
+    solver = BatchedChainLQR(n, m, T, batch)
+    assert host in solver.kernel_name and "embedding" in solver.kernel_name
+    sol, gains, status = solver.factor_solve(mats, vecs)
+    torch.cuda.synchronize()
+    ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats.cpu().numpy(), vecs.cpu().numpy())
+    np.testing.assert_array_equal(status.cpu().numpy(), ref_status)
+    ok = ref_status == 0
+    assert _rel(sol.cpu().numpy()[ok], ref_sol[ok]) <= 1e-9
+    if T > 0:
+        assert _rel(gains.cpu().numpy()[ok], ref_gains[ok]) <= 1e-9
+        g2, st2 = solver.factor(mats)
+        s2 = solver.solve(mats, vecs, g2)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(st2.cpu().numpy(), ref_status)
+        assert _rel(s2.cpu().numpy()[ok], ref_sol[ok]) <= 1e-9
+        assert _rel(g2.cpu().numpy()[ok], ref_gains[ok]) <= 1e-9
 
 
 def test_forced_general_engine_equals_fused_kernel(oracle_lib):
