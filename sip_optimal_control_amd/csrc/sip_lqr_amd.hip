@@ -125,6 +125,9 @@ const KernelEntry kKernels[] = {
     QW16_STAGED(8, 4),  QW16_STAGED(12, 2), QW16_DIRECT(4, 1),  QW16_DIRECT(4, 3),
     QW16_DIRECT(6, 1),  QW16_DIRECT(6, 3),  QW16_DIRECT(8, 1),  QW16_DIRECT(12, 1),
     QW16_DIRECT(12, 3),
+    // hosts for the embedding of larger shapes (n <= 15: one lane of the row carries the affine column)
+    QW16_STAGED(8, 8),  QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(14, 8), QW16_DIRECT(15, 4),
+    QW16_DIRECT(15, 8),
 };
 
 const KernelEntry *find_kernel(int dtype, int n, int m) {

@@ -60,6 +60,20 @@ def test_reference_benchmark_grid_has_fused_kernels(oracle_lib, n, m):
     assert _rel(sol, ref_sol) <= TOL and _rel(gains, ref_gains) <= TOL
 
 
+@pytest.mark.parametrize("n,m", [(8, 8), (12, 8), (14, 4), (14, 8), (15, 4), (15, 8)])
+def test_large_host_kernels(oracle_lib, n, m):
+    """The larger instantiations (hosts of the embedding of n <= 15, m <= 8 shapes)."""
+    from sip_optimal_control_amd import BatchedChainLQR
+    T, batch = 12, 9
+    name = BatchedChainLQR(n, m, T, batch, device="cuda:0").kernel_name
+    assert f"qw16<{n},{m}," in name and "embedding" not in name
+    shape, mats, vecs, sol, gains, status = _run(n, m, T, batch, seed=2000 + 10 * n + m)
+    ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats, vecs)
+    np.testing.assert_array_equal(status, ref_status)
+    assert (ref_status == 0).all()
+    assert _rel(sol, ref_sol) <= TOL and _rel(gains, ref_gains) <= TOL
+
+
 def test_kkt_residual_full_size(oracle_lib):
     """BASELINE C2 shape at full batch: KKT residual of every GPU solution."""
     from oracle import dense_kkt
