@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     const double *__restrict__ mats, const double *__restrict__ vecs,
     double *__restrict__ sol, double *__restrict__ gains,
     double *__restrict__ wsp, int *__restrict__ status, const long batch,
-    const int T SIP_STAMP_ARG) {
+    const int T, const int factor_only SIP_STAMP_ARG) {
   static_assert(N >= 1 && N <= 15, "vector lane needs N <= 15");
   static_assert(M >= 1 && M <= 16, "");
   using L = ChainLayout<N, M>;
@@ -659,6 +659,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   if (valid && c == 0)
     status[p] = stat;
 
+  if (factor_only) // split sip_lqr_factor(): gains and statuses only, no rollout
+    return;
   // The rollout reads W / g / K / k written above by other lanes of this
   // wave: workgroup-scope release/acquire (the block is one wavefront).
   __syncthreads();

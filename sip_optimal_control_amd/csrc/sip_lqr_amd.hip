@@ -27,7 +27,7 @@ struct sip_lqr_plan {
   // fused factor+solve launcher of a dedicated kernel; nullptr: the general
   // engine (tree_generic.hpp) runs factor then solve
   hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
-                          void *, void *, int32_t *, void *, hipStream_t);
+                          void *, void *, int32_t *, void *, hipStream_t, int);
   // General engine on the packed chain layout: serves shapes / dtypes without
   // a dedicated kernel and the split factor / solve entry points.  Tables are
   // laid out at plan creation (host only), uploaded at first use.
@@ -62,7 +62,7 @@ namespace {
 template <int N, int M, bool STAGED, bool WPACK>
 hipError_t launch_qw16(const sip_lqr_plan *pl, const void *mats,
                        const void *vecs, void *sol, void *gains,
-                       int32_t *status, void *ws, hipStream_t stream) {
+                       int32_t *status, void *ws, hipStream_t stream, int factor_only) {
   using Cfg = sipamd::StagedCfg<N, M, WPACK>;
   const long batch = pl->batch;
   const unsigned blocks = (unsigned)((batch + 3) / 4);
@@ -77,13 +77,13 @@ hipError_t launch_qw16(const sip_lqr_plan *pl, const void *mats,
   hipLaunchKernelGGL((sipamd::chain_factor_solve_qw16<N, M, STAGED, WPACK>),
                      dim3(blocks), dim3(64), lds, stream, (const double *)mats,
                      (const double *)vecs, (double *)sol, (double *)gains,
-                     (double *)ws, (int *)status, batch, pl->T SIP_STAMP_PASS);
+                     (double *)ws, (int *)status, batch, pl->T, factor_only SIP_STAMP_PASS);
   return hipGetLastError();
 }
 
 template <int M>
 hipError_t launch_mf32(const sip_lqr_plan *pl, const void *mats, const void *vecs, void *sol, void *gains,
-                       int32_t *status, void *ws, hipStream_t stream) {
+                       int32_t *status, void *ws, hipStream_t stream, int /*factor_only: full sweep*/) {
   hipLaunchKernelGGL((sipamd::mf32::chain_factor_solve_mf32<M>), dim3((unsigned)pl->batch), dim3(64), 0,
                      stream, (const float *)mats, (const float *)vecs, (float *)sol, (float *)gains,
                      (float *)ws, (int *)status, (long)pl->batch, pl->T SIP_STAMP_PASS);
@@ -95,7 +95,7 @@ struct KernelEntry {
   const char *name;
   int ws_slot;
   hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
-                          void *, void *, int32_t *, void *, hipStream_t);
+                          void *, void *, int32_t *, void *, hipStream_t, int);
 };
 
 // direct: every lane loads its columns from global memory (any N <= 15)
@@ -336,7 +336,7 @@ hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, 
       v = w + f.vecs;
     }
     if (e == hipSuccess)
-      e = p->launch_fs(p, mats, v, sol ? sol : (void *)(w + f.sol), gains, status, ws, s);
+      e = p->launch_fs(p, mats, v, sol ? sol : (void *)(w + f.sol), gains, status, ws, s, vecs == nullptr);
     return e;
   }
   const PadDims d = pad_dims(p);
@@ -350,7 +350,7 @@ hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, 
   else
     e = hipMemsetAsync(w + f.vecs, 0, f.sol - f.vecs, s);
   if (e == hipSuccess)
-    e = p->launch_fs(p, w + f.pmats, w + f.vecs, w + f.sol, w + f.pgains, status, ws, s);
+    e = p->launch_fs(p, w + f.pmats, w + f.vecs, w + f.sol, w + f.pgains, status, ws, s, vecs == nullptr);
   if (e == hipSuccess && sol != nullptr)
     hipLaunchKernelGGL(pad_vecs_kernel<false>, grid(B * d.vecs_len), dim3(256), 0, s, d, (const double *)(w + f.sol),
                        (double *)sol, B);
