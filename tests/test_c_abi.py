@@ -70,6 +70,35 @@ def test_plan_sizes_and_errors(lib):
     assert lib.sip_lqr_plan_create(7, 8, 5, 12, 4, 0, ctypes.byref(h)) == -1
 
 
+def test_kernel_selection_and_embedding(lib, monkeypatch):
+    """Host-side dispatch (no GPU needed): exact kernels for the reference's benchmark grid, the
+    smallest larger fused kernel for other uniform shapes, the general engine beyond."""
+    h = ctypes.c_void_p()
+
+    def name(n, m, dtype=0):
+        assert lib.sip_lqr_plan_create(dtype, 16, 10, n, m, 0, ctypes.byref(h)) == 0
+        out = lib.sip_lqr_kernel_name(h).decode()
+        ws = lib.sip_lqr_workspace_bytes(h)
+        lib.sip_lqr_plan_destroy(h)
+        return out, ws
+
+    for n in (4, 6, 8, 12):
+        for m in (1, 2, 3, 4):
+            kernel, _ = name(n, m)
+            assert f"qw16<{n},{m}," in kernel and "embedding" not in kernel
+            assert ("staged" in kernel) == (m % 2 == 0)
+    assert name(10, 3)[0] == "chain_factor_solve_qw16<12,4,staged>/f64 embedding (10,3)"
+    assert name(5, 3)[0].startswith("chain_factor_solve_qw16<6,4,staged>")
+    assert name(13, 5)[0].startswith("chain_factor_solve_qw16<14,8,staged>")
+    assert name(15, 7)[0].startswith("chain_factor_solve_qw16<15,8,direct>")
+    assert "tree_generic" in name(16, 4)[0] and "tree_generic" in name(12, 9)[0]
+    assert "tree_generic" in name(10, 3, dtype=1)[0]  # fp32: only the n = 32 kernel is dedicated
+    exact_ws, embedded_ws = name(12, 4)[1], name(10, 3)[1]
+    assert embedded_ws > exact_ws  # padded copies of mats / vecs / sol / gains live in the workspace
+    monkeypatch.setenv("SIP_LQR_PAD", "0")
+    assert "tree_generic" in name(10, 3)[0]
+
+
 def _tables(blocks):
     keep, tabs = [], {}
     for name, arrs in blocks.items():
