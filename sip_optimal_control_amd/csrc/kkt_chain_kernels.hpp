@@ -100,17 +100,22 @@ __device__ __forceinline__ void stage_copy2(double *dst, const double *__restric
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-template <bool WITH_RHS>
+// WITH_RHS: also q_mod / r_mod / c_mod from b.  MATS = false (the split solve path): ONLY those --
+// the Jacobians of the stage are staged, no Q_mod / M_mod / R_mod / A / B work, `status` problems
+// with a failed factorization are skipped.
+template <bool WITH_RHS, bool MATS = true>
 __global__ void __launch_bounds__(TPB)
 condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, const double *__restrict__ r1_all,
                       const double *__restrict__ inv_all, double *__restrict__ mats_all,
-                      const double *__restrict__ b_all, double *__restrict__ vecs_all, long batch) {
+                      const double *__restrict__ b_all, double *__restrict__ vecs_all, long batch,
+                      const int32_t *__restrict__ status = nullptr) {
+  static_assert(MATS || WITH_RHS, "nothing to do");
   extern __shared__ double sm[];
   const int n = ck.n, m = ck.m, T = ck.T;
   double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows;
   const long p = blockIdx.x / (T + 1);
   const int i = blockIdx.x - (unsigned)(p * (T + 1));
-  if (p >= batch)
+  if (p >= batch || (!MATS && status != nullptr && status[p] != 0))
     return;
   const int tid = threadIdx.x;
   const bool last = i == T;
@@ -133,7 +138,15 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
   // whole stage (node item + edge item are adjacent in the model arena) -> LDS,
   // and the weights 1/r2, 1/(w+r3) of its constraint rows: [node c | node g | edge c | edge g]
   const int edge_len = last ? 0 : ck.edge_len;
-  stage_copy2(buf, item, node_len + edge_len, tid);
+  if (MATS) {
+    stage_copy2(buf, item, node_len + edge_len, tid);
+  } else { // the Jacobian tails only, at their usual places in the image
+    stage_copy2(buf + nn, item + nn, (c + g) * n, tid);
+    if (!last) {
+      const int o_tail = node_len + 2 * nn + 2 * nm + m * m;
+      stage_copy2(buf + o_tail, item + o_tail, (ce + ge) * (n + m), tid);
+    }
+  }
   const int nrows = c + g + ce + ge;
   for (int k = tid; k < nrows; k += TPB) {
     double wk, bk = 0.0;
@@ -155,6 +168,7 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
   const double *Jxc = eb + o_j, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
   __syncthreads();
 
+  if (MATS)
   // ---- Q_mod, M_mod, R_mod (helpers.cpp:299-361) ----
   // T = J^T diag(w) J over the stage's combined columns [x (n) | u (m)] and all its constraint
   // rows, as 16 x 16 tiles on the fp64 matrix pipe (v_mfma_f64_16x16x4_f64: lane l feeds

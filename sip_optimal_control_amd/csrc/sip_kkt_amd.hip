@@ -178,7 +178,11 @@ hipError_t launch_merge(const sip_kkt_plan *p, const Regions &r, int32_t *status
 
 hipError_t launch_rhs(const sip_kkt_plan *p, const Regions &r, const double *model, const double *b,
                       const int32_t *status, hipStream_t s) {
-  if (p->staged)
+  if (p->chain_kernels)
+    hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false>), dim3(node_grid(p)),
+                       dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, p->ck, model, (const double *)nullptr,
+                       r.inv, r.in0, b, r.in1, (long)p->batch, status);
+  else if (p->staged)
     hipLaunchKernelGGL(sipamd::kkt::rhs_staged_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_rhs, s,
                        p->meta, model, b, r.inv, r.in1, status, (long)p->batch);
   else
