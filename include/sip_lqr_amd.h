@@ -74,6 +74,9 @@ enum {
 enum { SIP_LQR_F64 = 0, SIP_LQR_F32 = 1 };
 
 typedef struct sip_lqr_plan sip_lqr_plan;
+/* Threading: like the reference (no globals; distinct LQR + Workspace pairs are independent, a
+ * shared Workspace is not thread-safe), distinct plans may be used concurrently; one plan (and the
+ * device buffers handed to it) serves one host thread / one stream at a time. */
 
 /* Replaces: LQR::LQR(const Input&, Workspace&) + compile_topology()
  * (lqr.cpp:635-643) for `batch` problems of horizon T (= num_edges), state
