@@ -313,7 +313,12 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     double *__restrict__ sol, double *__restrict__ gains,
     double *__restrict__ wsp, int *__restrict__ status, const long batch,
     const int T, const int factor_only SIP_STAMP_ARG) {
-  static_assert(N >= 1 && N <= 15, "vector lane needs N <= 15");
+  // N = 16 fills the 16-lane row: no lane is left for the affine column, so the vectors of
+  // LQR::solve's backward sweep are kept DISTRIBUTED (lane r holds element r) and every
+  // matrix-vector product of the sweep is one dotv block (VDIST mode; direct loads only).
+  constexpr bool VDIST = N == 16;
+  static_assert(N >= 1 && N <= 16, "one problem per 16-lane row");
+  static_assert(!(VDIST && STAGED), "N = 16 is instantiated without LDS staging");
   static_assert(M >= 1 && M <= 16, "");
   using L = ChainLayout<N, M>;
   using C = StagedCfg<N, M, WPACK>;
@@ -367,6 +372,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
 
   int stat = 0;
   double W[N], V[N], t[N], vch[N];
+  double vd = 0.0, td = 0.0, qd = 0.0; // VDIST: v, t = c - delta o v, q of the current node (element c)
+  auto sum4 = [](const double (&a)[4]) { return (a[0] + a[1]) + (a[2] + a[3]); };
 
   // Buffer view of this wave's rows of the workspace (packed-W spill).
   const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -397,6 +404,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       constexpr int r = decltype(ii)::value;
       Vq[r] = src[r];
     });
+    if constexpr (VDIST)
+      qd = nv[cm];
   };
 
   // Common tail of every node: statuses, F/W (lqr.cpp:722-727 + 689), the
@@ -406,10 +415,12 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   // (meaningful on the vector lane) c and delta as columns.
   struct NodeTail {
     double dl, cv[N], dv[N];
+    double cd; // VDIST: c_c of the node, one per lane
   };
   auto load_tail = [&](auto nm, auto nv, NodeTail &nt) {
     const double d = nm[N * N + cm];
     nt.dl = isM ? d : 1.0;
+    nt.cd = VDIST ? nv[N + cm] : 0.0;
     if constexpr (std::is_same_v<decltype(nm), lds_cdouble *>) {
       auto csrc = isV ? nv + N : zeros, dsrc = isV ? nm + N * N : zeros;
       sfor<0, N>([&](auto ii) {
@@ -452,11 +463,20 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
         vch[r] = V[r];
       });
     }
+    if constexpr (VDIST)
+      td = nt.cd - dl * vd; // t = c - delta o v (-f of lqr.cpp:778-779), element c
     SIP_SEG(7);
     const bool ffail = node_factor<N>(V, dl, c, E, tv, W, X);
     SIP_SEG(8);
     if (stat == 0 && ffail)
       stat = 2; // F_FACTORIZATION_FAILURE
+    if constexpr (VDIST) { // h = S D^{-1/2} (c - delta o v): row c of the symmetric S is this lane's column
+      const double phi = rsqrt_nr(dl) * td;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      dotv<N, true>(acc, phi, X);
+      if (valid)
+        pw[(long)i * WSN + WG + N + c] = sum4(acc);
+    }
     if (valid && isV) { // h = S D^{-1/2} (c - delta o v)
       double *hn = pw + (long)i * WSN + WG + N;
       sfor<0, N>([&](auto ii) { hn[decltype(ii)::value] = X[decltype(ii)::value]; });
@@ -527,6 +547,14 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       sfor<0, N>(
           [&](auto ii) { gn[decltype(ii)::value] = F[decltype(ii)::value]; });
     }
+    double gd = 0.0, hd = 0.0, hf[M], kf[M]; // VDIST: g (element c), h (element c < M), h and k replicated
+    if constexpr (VDIST) { // g = v_c + W t  (lqr.cpp:780-781 with t = -f)
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      dotv<N, true>(acc, td, W);
+      gd = vd + sum4(acc);
+      if (valid)
+        pw[(long)(i + 1) * WSN + WG + c] = gd;
+    }
     SIP_SEG(2);
     asm volatile("" ::: "memory");
     double Vn[N];
@@ -544,6 +572,11 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
 
     // [H | h] = [M^T | r] + B^T [F | g]   (lqr.cpp:704-705, :783-784)
     spreadx<M, N, false>(H, Bcol, F);
+    if constexpr (VDIST) { // h = r + B^T g  (lqr.cpp:783-784); lane j < M holds h_j
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      dotv<N, true>(acc, gd, Bcol);
+      hd = nv[L::VNODE + cu] + sum4(acc);
+    }
     asm volatile("" ::: "memory");
     load_tail(nm, nv, nt); // c, delta: in flight behind the gain solve
     // [K | k] = -G^{-1} [H | h]   (lqr.cpp:707-713, :785-791)
@@ -557,6 +590,37 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       sfor<0, M>(
           [&](auto jj) { gi[decltype(jj)::value] = K[decltype(jj)::value]; });
     }
+    if constexpr (VDIST) {
+      // k = -G^{-1} h  (lqr.cpp:785-791) on a replicated copy of h: every lane gathers h and the
+      // strictly lower part of Lt (lane i holds column i), then runs ldl_solve_dpp's recurrences
+      //   w_j = (h_j - sum_{i<j} Lt(j,i) w_i) / d_j,   x_j = w_j - (sum_{i>j} Lt(i,j) x_i) / d_j
+      double Lf[M][M];
+      sfor<0, M>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        hf[j] = bcast<j>(hd);
+        sfor<0, j>([&](auto iv) {
+          constexpr int i2 = decltype(iv)::value;
+          Lf[j][i2] = bcast<i2>(G[j]); // Lt(j, i), j > i
+        });
+      });
+      sfor<0, M>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        double w = hf[j];
+        sfor<0, j>([&](auto iv) { w = __builtin_fma(-Lf[j][decltype(iv)::value], kf[decltype(iv)::value], w); });
+        kf[j] = w * rinvG[j];
+      });
+      sfor_down<M - 1, -1>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        double a = 0.0;
+        sfor<j + 1, M>([&](auto iv) { a = __builtin_fma(Lf[decltype(iv)::value][j], kf[decltype(iv)::value], a); });
+        kf[j] = __builtin_fma(-rinvG[j], a, kf[j]);
+      });
+      sfor<0, M>([&](auto jj) { kf[decltype(jj)::value] = -kf[decltype(jj)::value]; });
+      if (valid && c == 0) {
+        double *gk = pg + (long)i * L::GAIN + N * M;
+        sfor<0, M>([&](auto jj) { gk[decltype(jj)::value] = kf[decltype(jj)::value]; });
+      }
+    }
 
     SIP_SEG(5);
     // [V | v] = [Q | q] + A^T [F | g] + K^T [H | h]  (lqr.cpp:715-719,:793-794)
@@ -565,6 +629,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     spreadx<N, M, true>(Vn, K, H);
     sfor<0, N>(
         [&](auto ii) { V[decltype(ii)::value] = Vn[decltype(ii)::value]; });
+    if constexpr (VDIST) { // v = q + A^T g + K^T h  (lqr.cpp:793-794), element c
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      dotv<N, true>(acc, gd, Aaug);
+      double kh = 0.0;
+      sfor<0, M>([&](auto jj) { kh = __builtin_fma(K[decltype(jj)::value], hf[decltype(jj)::value], kh); });
+      vd = qd + sum4(acc) + kh;
+    }
     SIP_SEG(6);
     asm volatile("" ::: "memory");
   };
@@ -586,6 +657,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   {
     NodeTail nt;
     load_vq(pm + (long)T * STG, pv + (long)T * VSTG, V);
+    if constexpr (VDIST)
+      vd = qd; // v_T = q_T
     load_tail(pm + (long)T * STG, pv + (long)T * VSTG, nt);
     finish_node(T, nt);
   }
@@ -638,7 +711,12 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
 
   SIP_STAMP(ts_bwd);
   // ---- root: g_0 = v_0 + W_0 (c_0 - delta_0 o v_0)  (lqr.cpp:798-819) -----
-  {
+  if constexpr (VDIST) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    dotv<N, true>(acc, td, W);
+    if (valid)
+      pw[WG + c] = vd + sum4(acc);
+  } else {
     double F[N], tt[N];
     sfor<0, N>([&](auto ii) {
       constexpr int r = decltype(ii)::value;

@@ -128,6 +128,8 @@ const KernelEntry kKernels[] = {
     // hosts for the embedding of larger shapes (n <= 15: one lane of the row carries the affine column)
     QW16_STAGED(8, 8),  QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(14, 8), QW16_DIRECT(15, 4),
     QW16_DIRECT(15, 8),
+    // n = 16 (in the reference's benchmark grid): distributed-vector mode, see chain_qw16.hpp
+    QW16_DIRECT(16, 1), QW16_DIRECT(16, 2), QW16_DIRECT(16, 3), QW16_DIRECT(16, 4), QW16_DIRECT(16, 8),
 };
 
 const KernelEntry *find_kernel(int dtype, int n, int m) {

@@ -91,7 +91,8 @@ def test_kernel_selection_and_embedding(lib, monkeypatch):
     assert name(5, 3)[0].startswith("chain_factor_solve_qw16<6,4,staged>")
     assert name(13, 5)[0].startswith("chain_factor_solve_qw16<14,8,staged>")
     assert name(15, 7)[0].startswith("chain_factor_solve_qw16<15,8,direct>")
-    assert "tree_generic" in name(16, 4)[0] and "tree_generic" in name(12, 9)[0]
+    assert "qw16<16,4,direct>" in name(16, 4)[0]  # distributed-vector mode
+    assert "tree_generic" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
     assert "tree_generic" in name(10, 3, dtype=1)[0]  # fp32: only the n = 32 kernel is dedicated
     exact_ws, embedded_ws = name(12, 4)[1], name(10, 3)[1]
     assert embedded_ws > exact_ws  # padded copies of mats / vecs / sol / gains live in the workspace

@@ -45,11 +45,11 @@ def test_factor_solve_matches_oracle(oracle_lib, n, m, T, batch):
         assert _rel(gains, ref_gains) <= TOL
 
 
-@pytest.mark.parametrize("n", [4, 6, 8, 12])
+@pytest.mark.parametrize("n", [4, 6, 8, 12, 16])
 @pytest.mark.parametrize("m", [1, 2, 3, 4])
 def test_reference_benchmark_grid_has_fused_kernels(oracle_lib, n, m):
     """The (state_dim, control_dim) grid of the reference's benchmarks (lqr_benchmark.cpp:537-545,
-    newton_kkt_benchmark.cpp:264-273; n = 16 runs on the general engine) on dedicated kernels."""
+    newton_kkt_benchmark.cpp:264-273) on dedicated kernels; n = 16 in distributed-vector mode."""
     from sip_optimal_control_amd import BatchedChainLQR
     T, batch = 16, 13
     assert "qw16" in BatchedChainLQR(n, m, T, batch, device="cuda:0").kernel_name
@@ -60,7 +60,7 @@ def test_reference_benchmark_grid_has_fused_kernels(oracle_lib, n, m):
     assert _rel(sol, ref_sol) <= TOL and _rel(gains, ref_gains) <= TOL
 
 
-@pytest.mark.parametrize("n,m", [(8, 8), (12, 8), (14, 4), (14, 8), (15, 4), (15, 8)])
+@pytest.mark.parametrize("n,m", [(8, 8), (12, 8), (14, 4), (14, 8), (15, 4), (15, 8), (16, 8)])
 def test_large_host_kernels(oracle_lib, n, m):
     """The larger instantiations (hosts of the embedding of n <= 15, m <= 8 shapes)."""
     from sip_optimal_control_amd import BatchedChainLQR

@@ -29,7 +29,7 @@ def _make(n, m, T, batch, seed, dtype=None):
                                       dtype=dtype, cross_term=0.01)
 
 
-@pytest.mark.parametrize("n,m,T,batch", [(16, 4, 16, 5), (5, 3, 7, 9), (7, 1, 4, 3), (15, 16, 3, 2)])
+@pytest.mark.parametrize("n,m,T,batch", [(17, 4, 16, 5), (5, 3, 7, 9), (7, 1, 4, 3), (15, 16, 3, 2)])
 def test_general_engine_fp64_matches_oracle(oracle_lib, monkeypatch, n, m, T, batch):
     from sip_optimal_control_amd import BatchedChainLQR
     monkeypatch.setenv("SIP_LQR_PAD", "0")  # no embedding in a larger fused kernel
@@ -48,7 +48,7 @@ def test_general_engine_fp64_matches_oracle(oracle_lib, monkeypatch, n, m, T, ba
     (5, 3, 7, 9, "<6,4,staged>"), (7, 1, 4, 3, "<8,2,staged>"), (10, 3, 20, 13, "<12,4,staged>"),
     (11, 4, 12, 5, "<12,4,staged>"), (9, 2, 9, 7, "<12,2,staged>"), (3, 1, 6, 4, "<3,2,direct>"),
     (5, 3, 0, 2, "<6,4,staged>"), (13, 4, 10, 6, "<14,4,staged>"), (13, 5, 8, 5, "<14,8,staged>"),
-    (10, 6, 8, 5, "<12,8,staged>"), (15, 3, 5, 3, "<15,4,direct>")])
+    (10, 6, 8, 5, "<12,8,staged>"), (15, 3, 5, 3, "<15,4,direct>"), (16, 6, 6, 5, "<16,8,direct>")])
 def test_embedding_in_the_next_fused_kernel(oracle_lib, n, m, T, batch, host):
     """Uniform shapes without an exact kernel run on the next larger fused kernel: the extra states
     and controls decouple exactly, so the real components match the oracle as usual.  Fused and
