@@ -86,10 +86,12 @@ def test_offsets_match_the_reference_ordering():
         assert [kkt.model_offset(len(NODE_BLOCKS) + b, e) for e in range(dims.E)] == dims.edge_off[name]
 
 
-@pytest.mark.parametrize("n,m,T,batch", [(4, 2, 16, 64), (12, 4, 50, 32), (8, 3, 20, 16), (6, 2, 12, 8)])
+@pytest.mark.parametrize("n,m,T,batch", [(4, 2, 16, 64), (12, 4, 50, 32), (8, 3, 20, 16), (6, 2, 12, 8),
+                                         (16, 4, 10, 8), (13, 5, 6, 4), (20, 3, 5, 3)])
 def test_newton_kkt_benchmark_shapes(n, m, T, batch):
-    """Uniform chains (benchmarks/newton_kkt_benchmark.cpp:58-83): packed chain layout, fused
-    kernels where the shape has one (12,4 / 4,2 / 8,3), the general engine otherwise (6,2)."""
+    """Uniform chains (benchmarks/newton_kkt_benchmark.cpp:58-83): packed chain layout; the Riccati
+    part on an exact fused kernel, on an embedding (13,5), or on the general engine (20,3).  n + m > 16
+    exercises the multi-tile rank updates of the chain condensation kernel."""
     dims = rk.newton_kkt_dims(n, m, T)
     arrays = rk.newton_kkt_problem(dims, seed=100 * n + m, batch=batch, r2_max=1e2)
     kkt = _make(dims, batch)
