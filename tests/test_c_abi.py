@@ -178,3 +178,13 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "lqr_oracle" not in text and "from oracle" not in text and \
                     "import oracle" not in text, f
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: both headers must compile as C99 (no C++-only constructs)."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "sip_lqr_amd.h"\n#include "sip_kkt_amd.h"\n'
+                   "int main(void) { return (int)sizeof(sip_lqr_plan *) - (int)sizeof(sip_kkt_plan *); }\n")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])
