@@ -132,6 +132,92 @@ theta_schur_kernel(const Meta mt, const ThetaMeta th, const double *__restrict__
     S_all[prob * p * p + q] = sm[q];
 }
 
+// Same, for p <= PMAX: the lanes stride over the rows r of J / K^-1 J (coalesced: consecutive rows of
+// a column are contiguous) and keep all p x p partial sums in registers; one butterfly reduction at
+// the end.  (The generic kernel above walks each (a, b) pair's two columns with one lane.)
+template <int PMAX>
+__global__ void __launch_bounds__(TPB)
+theta_schur_small_kernel(const Meta mt, const ThetaMeta th, const double *__restrict__ theta_all,
+                         const double *__restrict__ r1_all, const double *__restrict__ J_all,
+                         const double *__restrict__ KJ_all, double *__restrict__ S_all,
+                         int32_t *__restrict__ status, long batch, int fail_code) {
+  __shared__ double sm[PMAX * PMAX];
+  const long prob = blockIdx.x;
+  if (prob >= batch || status[prob] != 0)
+    return;
+  const int tid = threadIdx.x, p = th.p, sx = mt.x_dim;
+  const long skkt = (long)sx + mt.y_dim + mt.z_dim, col_stride = batch * skkt;
+  const double *tm = theta_all + prob * th.theta_len;
+  const double *Jp = J_all + prob * skkt, *KJp = KJ_all + prob * skkt;
+  double acc[PMAX][PMAX];
+#pragma unroll
+  for (int a = 0; a < PMAX; ++a)
+#pragma unroll
+    for (int b = 0; b < PMAX; ++b)
+      acc[a][b] = 0.0;
+  for (long r = tid; r < skkt; r += TPB) {
+    double ja[PMAX], kb[PMAX];
+#pragma unroll
+    for (int a = 0; a < PMAX; ++a) {
+      ja[a] = a < p ? Jp[a * col_stride + r] : 0.0;
+      kb[a] = a < p ? KJp[a * col_stride + r] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < PMAX; ++a)
+#pragma unroll
+      for (int b = 0; b < PMAX; ++b)
+        acc[a][b] += ja[a] * kb[b];
+  }
+#pragma unroll
+  for (int a = 0; a < PMAX; ++a)
+#pragma unroll
+    for (int b = 0; b < PMAX; ++b) {
+      double v = acc[a][b];
+      for (int off = TPB / 2; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, TPB);
+      if (tid == 0 && a < p && b < p)
+        sm[a + p * b] = v;
+    }
+  __syncthreads();
+  for (int q = tid; q < p * p; q += TPB) {
+    const int b = q / p, a = q - b * p;
+    double base = 0.0;
+    for (int i = 0; i < mt.N; ++i)
+      base += (tm + th.to[TH_N_TT][i])[q];
+    for (int e = 0; e < mt.E; ++e)
+      base += (tm + th.to[TH_E_TT][e])[q];
+    if (a == b)
+      base += r1_all[prob * (sx + p) + sx + a];
+    sm[q] = base - sm[q];
+  }
+  __syncthreads();
+  if (tid == 0) { // Eigen::LLT, lower, in place: pivot <= 0 -> NumericalIssue
+    bool ok = true;
+    for (int k = 0; k < p && ok; ++k) {
+      double d = sm[k + p * k];
+      for (int j = 0; j < k; ++j)
+        d -= sm[k + p * j] * sm[k + p * j];
+      if (!(d > 0.0)) {
+        ok = false;
+        break;
+      }
+      d = sqrt(d);
+      sm[k + p * k] = d;
+      for (int r = k + 1; r < p; ++r) {
+        double v = sm[r + p * k];
+        for (int j = 0; j < k; ++j)
+          v -= sm[r + p * j] * sm[k + p * j];
+        sm[r + p * k] = v / d;
+      }
+    }
+    if (!ok)
+      status[prob] = fail_code;
+  }
+  __syncthreads();
+  for (int q = tid; q < p * p; q += TPB)
+    S_all[prob * p * p + q] = sm[q];
+}
+
 // b = [x | theta | y | z] -> stagewise [x | y | z]  (helpers.cpp:911-916)
 __global__ void __launch_bounds__(256)
 theta_strip_kernel(const double *__restrict__ b_all, double *__restrict__ out_all, int sx, int p, long skkt,
@@ -160,12 +246,15 @@ theta_finish_kernel(const Meta mt, const ThetaMeta th, const double *__restrict_
   const double *Jp = J_all + prob * skkt, *KJp = KJ_all + prob * skkt, *sw = sw_all + prob * skkt;
   const double *b_theta = b_all + prob * (skkt + p) + sx;
   double *sol = sol_all + prob * (skkt + p);
-  for (int a = tid; a < p; a += TPB) {
+  for (int a = 0; a < p; ++a) { // J_theta^T K^-1 b: lanes over the rows (coalesced), butterfly sum
     const double *ja = Jp + a * col_stride;
     double dot = 0.0;
-    for (long r = 0; r < skkt; ++r)
+    for (long r = tid; r < skkt; r += TPB)
       dot += ja[r] * sw[r];
-    sm[a] = b_theta[a] - dot;
+    for (int off = TPB / 2; off > 0; off >>= 1)
+      dot += __shfl_xor(dot, off, TPB);
+    if (tid == 0)
+      sm[a] = b_theta[a] - dot;
   }
   __syncthreads();
   if (tid == 0) {

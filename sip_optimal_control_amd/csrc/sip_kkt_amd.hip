@@ -712,9 +712,14 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
     if (rc != SIP_LQR_OK)
       return rc;
   }
-  hipLaunchKernelGGL(sipamd::kkt::theta_schur_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
-                     sizeof(double) * (size_t)th * th, s, p->meta, p->theta_meta, d_theta, d_r1, t.J, t.KJ, t.S,
-                     d_status, (long)p->batch, (int)SIP_KKT_THETA_SCHUR_FAILURE);
+  if (th <= 8)
+    hipLaunchKernelGGL(sipamd::kkt::theta_schur_small_kernel<8>, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
+                       0, s, p->meta, p->theta_meta, d_theta, d_r1, t.J, t.KJ, t.S, d_status, (long)p->batch,
+                       (int)SIP_KKT_THETA_SCHUR_FAILURE);
+  else
+    hipLaunchKernelGGL(sipamd::kkt::theta_schur_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
+                       sizeof(double) * (size_t)th * th, s, p->meta, p->theta_meta, d_theta, d_r1, t.J, t.KJ, t.S,
+                       d_status, (long)p->batch, (int)SIP_KKT_THETA_SCHUR_FAILURE);
   return report(hipGetLastError(), "sip_kkt_factor_theta(schur)");
 }
 

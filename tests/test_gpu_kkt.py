@@ -274,7 +274,7 @@ def test_theta_schur_reference_case():
     assert (out[1] == 3.0).all() and np.abs(out[0] - sol[0]).max() <= 1e-12
 
 
-@pytest.mark.parametrize("n,m,T,p", [(6, 2, 10, 4), (12, 4, 20, 8)])
+@pytest.mark.parametrize("n,m,T,p", [(6, 2, 10, 4), (12, 4, 20, 8), (4, 1, 5, 9)])
 def test_theta_on_benchmark_chains(n, m, T, p):
     """NewtonKKTProblem(n, m, T, p) (newton_kkt_benchmark.cpp:58-262, the Theta benchmarks)."""
     base = rk.newton_kkt_dims(n, m, T)
