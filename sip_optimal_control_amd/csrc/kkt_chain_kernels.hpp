@@ -108,7 +108,11 @@ __global__ void __launch_bounds__(TPB)
 condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, const double *__restrict__ r1_all,
                       const double *__restrict__ inv_all, double *__restrict__ mats_all,
                       const double *__restrict__ b_all, double *__restrict__ vecs_all, long batch,
-                      const int32_t *__restrict__ status = nullptr) {
+                      const int32_t *__restrict__ status = nullptr, const int ncols = 1,
+                      const long b_col_stride = 0, const long vecs_col_stride = 0) {
+  // ncols > 1 (the columns of J_theta, helpers.cpp:414-747): column j's right-hand side is
+  // b_all + j * b_col_stride, its q_mod / r_mod / c_mod go to vecs_all + j * vecs_col_stride; the
+  // Jacobians of the stage are staged once for all columns.
   static_assert(MATS || WITH_RHS, "nothing to do");
   extern __shared__ double sm[];
   const int n = ck.n, m = ck.m, T = ck.T;
@@ -148,19 +152,29 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
     }
   }
   const int nrows = c + g + ce + ge;
-  for (int k = tid; k < nrows; k += TPB) {
-    double wk, bk = 0.0;
+  // entry of the right-hand side that belongs to constraint row k of this stage
+  auto rhs_row = [&](const int k, const double *by, const double *bz) {
     if (k < c)
-      wk = yinv[y_nc + k], bk = WITH_RHS ? b_y[y_nc + k] : 0.0;
+      return by[y_nc + k];
+    if (k < c + g)
+      return bz[z_n + (k - c)];
+    if (k < c + g + ce)
+      return by[y_ec + (k - c - g)];
+    return bz[z_e + (k - c - g - ce)];
+  };
+  for (int k = tid; k < nrows; k += TPB) {
+    double wk;
+    if (k < c)
+      wk = yinv[y_nc + k];
     else if (k < c + g)
-      wk = zinv[z_n + (k - c)], bk = WITH_RHS ? b_z[z_n + (k - c)] : 0.0;
+      wk = zinv[z_n + (k - c)];
     else if (k < c + g + ce)
-      wk = yinv[y_ec + (k - c - g)], bk = WITH_RHS ? b_y[y_ec + (k - c - g)] : 0.0;
+      wk = yinv[y_ec + (k - c - g)];
     else
-      wk = zinv[z_e + (k - c - g - ce)], bk = WITH_RHS ? b_z[z_e + (k - c - g - ce)] : 0.0;
+      wk = zinv[z_e + (k - c - g - ce)];
     wl[k] = wk;
     if (WITH_RHS)
-      wr[k] = wk * bk; // weights(constraint) * rhs(constraint), helpers.cpp:143
+      wr[k] = wk * rhs_row(k, b_y, b_z); // weights(constraint) * rhs(constraint), helpers.cpp:143
   }
   const double *Jc = buf + nn, *Jg = Jc + c * n;
   const double *eb = buf + node_len; // edge item
@@ -239,22 +253,32 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
   }
   if (WITH_RHS) { // q_mod, c_mod, r_mod (helpers.cpp:752-812)
     const double *wr_n = wr, *wr_e = wr + c + g;
-    if (tid < n) {
-      double acc = -b[i * (n + m) + tid];
-      acc = dot_seq<true>(acc, Jc + c * tid, wr_n, c);
-      acc = dot_seq<true>(acc, Jg + g * tid, wr_n + c, g);
-      if (!last) {
-        acc = dot_seq<true>(acc, Jxc + ce * tid, wr_e, ce);
-        acc = dot_seq<true>(acc, Jxg + ge * tid, wr_e + ce, ge);
+    for (int col = 0; col < ncols; ++col) {
+      const double *bc = b + col * b_col_stride, *bc_y = bc + ck.x_dim, *bc_z = bc_y + ck.y_dim;
+      double *vc = vecs + col * vecs_col_stride;
+      if (col > 0) { // weighted right-hand side rows of this column
+        __syncthreads();
+        for (int k = tid; k < nrows; k += TPB)
+          wr[k] = wl[k] * rhs_row(k, bc_y, bc_z);
+        __syncthreads();
       }
-      vecs[tid] = acc;
-      vecs[n + tid] = -b_y[y_dyn + tid];
-    } else if (!last && tid >= 32 && tid - 32 < m) { // another half of the wave: r_mod
-      const int d = tid - 32;
-      double acc = -b[i * (n + m) + n + d];
-      acc = dot_seq<true>(acc, Juc + ce * d, wr_e, ce);
-      acc = dot_seq<true>(acc, Jug + ge * d, wr_e + ce, ge);
-      vecs[2 * n + d] = acc;
+      if (tid < n) {
+        double acc = -bc[i * (n + m) + tid];
+        acc = dot_seq<true>(acc, Jc + c * tid, wr_n, c);
+        acc = dot_seq<true>(acc, Jg + g * tid, wr_n + c, g);
+        if (!last) {
+          acc = dot_seq<true>(acc, Jxc + ce * tid, wr_e, ce);
+          acc = dot_seq<true>(acc, Jxg + ge * tid, wr_e + ce, ge);
+        }
+        vc[tid] = acc;
+        vc[n + tid] = -bc_y[y_dyn + tid];
+      } else if (!last && tid >= 32 && tid - 32 < m) { // another half of the wave: r_mod
+        const int d = tid - 32;
+        double acc = -bc[i * (n + m) + n + d];
+        acc = dot_seq<true>(acc, Juc + ce * d, wr_e, ce);
+        acc = dot_seq<true>(acc, Jug + ge * d, wr_e + ce, ge);
+        vc[2 * n + d] = acc;
+      }
     }
   }
 }
@@ -263,7 +287,9 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
 __global__ void __launch_bounds__(TPB)
 recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, const double *__restrict__ b_all,
                      const double *__restrict__ inv_all, const double *__restrict__ lqr_sol_all,
-                     double *__restrict__ sol_all, const int32_t *__restrict__ status, long batch) {
+                     double *__restrict__ sol_all, const int32_t *__restrict__ status, long batch,
+                     const int ncols = 1, const long b_col_stride = 0, const long lqr_col_stride = 0,
+                     const long sol_col_stride = 0) {
   extern __shared__ double sm[];
   const int n = ck.n, m = ck.m, T = ck.T;
   const long p = blockIdx.x / (T + 1);
@@ -280,39 +306,43 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
   const double *yinv = inv_all + p * ((long)ck.y_dim + ck.z_dim), *zinv = yinv + ck.y_dim;
   const int y_dyn = i * (n + ck.cn), y_nc = y_dyn + n, y_ec = T * (n + ck.cn) + n + ck.cT + i * ck.ce;
   const int z_n = i * ck.gn, z_e = T * ck.gn + ck.gT + i * ck.ge;
-  const double *b_y = b_all + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
-  const double *ls = lqr_sol_all + p * ck.vecs_len + (long)i * ck.vecs_stage; // x_i | y_i | u_i
-  double *sol = sol_all + p * kkt, *sol_y = sol + ck.x_dim, *sol_z = sol_y + ck.y_dim;
   double *jn = sm, *je = jn + (c + g) * n, *xs = sm + ck.lds_tail, *us = xs + n;
   stage_copy2(jn, item + nn, (c + g) * n, tid); // [dc_dx | dg_dx] of the node
   if (!last)
     stage_copy2(je, item + nn + (c + g) * n + 2 * nn + 2 * nm + m * m, (ce + ge) * (n + m), tid);
-  if (tid < n) {
-    const double xv = ls[tid];
-    xs[tid] = xv;
-    sol[i * (n + m) + tid] = xv;
-    sol_y[y_dyn + tid] = ls[n + tid];
-  } else if (!last && tid >= 32 && tid - 32 < m) {
-    const double uv = ls[2 * n + (tid - 32)];
-    us[tid - 32] = uv;
-    sol[i * (n + m) + n + (tid - 32)] = uv;
-  }
-  __syncthreads();
-  for (int k = tid; k < c + g; k += TPB) {
-    if (k < c)
-      sol_y[y_nc + k] = (row_dot(jn, k, c, n, xs) - b_y[y_nc + k]) * yinv[y_nc + k];
-    else
-      sol_z[z_n + (k - c)] = (row_dot(jn + c * n, k - c, g, n, xs) - b_z[z_n + (k - c)]) * zinv[z_n + (k - c)];
-  }
   const double *Jxc = je, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
-  for (int k = tid; k < ce + ge; k += TPB) {
-    if (k < ce) {
-      const double jx = row_dot(Jxc, k, ce, n, xs), ju = row_dot(Juc, k, ce, m, us);
-      sol_y[y_ec + k] = ((jx + ju) - b_y[y_ec + k]) * yinv[y_ec + k];
-    } else {
-      const int kk = k - ce;
-      const double jx = row_dot(Jxg, kk, ge, n, xs), ju = row_dot(Jug, kk, ge, m, us);
-      sol_z[z_e + kk] = ((jx + ju) - b_z[z_e + kk]) * zinv[z_e + kk];
+  for (int col = 0; col < ncols; ++col) { // ncols > 1: the columns of K^-1 J_theta, Jacobians staged once
+    const double *b_y = b_all + col * b_col_stride + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
+    const double *ls = lqr_sol_all + col * lqr_col_stride + p * ck.vecs_len + (long)i * ck.vecs_stage; // x_i | y_i | u_i
+    double *sol = sol_all + col * sol_col_stride + p * kkt, *sol_y = sol + ck.x_dim, *sol_z = sol_y + ck.y_dim;
+    if (col > 0)
+      __syncthreads(); // the previous column's readers of xs / us are done
+    if (tid < n) {
+      const double xv = ls[tid];
+      xs[tid] = xv;
+      sol[i * (n + m) + tid] = xv;
+      sol_y[y_dyn + tid] = ls[n + tid];
+    } else if (!last && tid >= 32 && tid - 32 < m) {
+      const double uv = ls[2 * n + (tid - 32)];
+      us[tid - 32] = uv;
+      sol[i * (n + m) + n + (tid - 32)] = uv;
+    }
+    __syncthreads();
+    for (int k = tid; k < c + g; k += TPB) {
+      if (k < c)
+        sol_y[y_nc + k] = (row_dot(jn, k, c, n, xs) - b_y[y_nc + k]) * yinv[y_nc + k];
+      else
+        sol_z[z_n + (k - c)] = (row_dot(jn + c * n, k - c, g, n, xs) - b_z[z_n + (k - c)]) * zinv[z_n + (k - c)];
+    }
+    for (int k = tid; k < ce + ge; k += TPB) {
+      if (k < ce) {
+        const double jx = row_dot(Jxc, k, ce, n, xs), ju = row_dot(Juc, k, ce, m, us);
+        sol_y[y_ec + k] = ((jx + ju) - b_y[y_ec + k]) * yinv[y_ec + k];
+      } else {
+        const int kk = k - ce;
+        const double jx = row_dot(Jxg, kk, ge, n, xs), ju = row_dot(Jug, kk, ge, m, us);
+        sol_z[z_e + kk] = ((jx + ju) - b_z[z_e + kk]) * zinv[z_e + kk];
+      }
     }
   }
 }

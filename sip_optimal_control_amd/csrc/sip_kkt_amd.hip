@@ -604,7 +604,7 @@ int sip_kkt_add_Kx_to_y(const sip_kkt_plan *p, const double *d_model, const doub
 namespace {
 
 struct ThetaRegions {
-  double *J, *KJ, *S, *rhs_sw, *sol_sw;
+  double *J, *KJ, *S, *rhs_sw, *sol_sw, *vecs_cols, *lsol_cols; // the last two: chain plans only
 };
 ThetaRegions theta_regions(const sip_kkt_plan *p, void *theta_work) {
   const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, B = (size_t)p->batch;
@@ -615,7 +615,10 @@ ThetaRegions theta_regions(const sip_kkt_plan *p, void *theta_work) {
   r.KJ = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt * p->theta_dim);
   r.S = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * p->theta_dim * p->theta_dim);
   r.rhs_sw = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt);
-  r.sol_sw = (double *)(w + cur);
+  r.sol_sw = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt);
+  const size_t cols = p->chain_kernels ? sizeof(double) * B * (size_t)p->in1_len * p->theta_dim : 0;
+  r.vecs_cols = (double *)(w + cur), cur = align256(cur + cols);
+  r.lsol_cols = (double *)(w + cur);
   return r;
 }
 
@@ -679,8 +682,9 @@ size_t sip_kkt_theta_work_bytes(const sip_kkt_plan *p) {
   if (p == nullptr || p->theta_dim < 1)
     return 0;
   const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, B = (size_t)p->batch, th = (size_t)p->theta_dim;
+  const size_t cols = p->chain_kernels ? align256(sizeof(double) * B * (size_t)p->in1_len * th) : 0;
   return 2 * align256(sizeof(double) * B * skkt * th) + align256(sizeof(double) * B * th * th) +
-         2 * align256(sizeof(double) * B * skkt);
+         2 * align256(sizeof(double) * B * skkt) + 2 * cols;
 }
 
 int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const double *d_theta, const double *d_w,
@@ -706,11 +710,35 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
                      p->theta_meta, d_theta, t.J, (long)p->batch);
   if ((e = hipGetLastError()) != hipSuccess)
     return report(e, "sip_kkt_factor_theta(jacobian)");
-  for (int col = 0; col < th; ++col) { // K^-1 J_theta, one column per launch (helpers.cpp:387)
-    rc = sip_kkt_solve(p, d_model, t.J + (size_t)col * p->batch * skkt, t.KJ + (size_t)col * p->batch * skkt, d_work,
-                       d_status, stream);
-    if (rc != SIP_LQR_OK)
-      return rc;
+  if (p->chain_kernels) {
+    // K^-1 J_theta (helpers.cpp:387): the right-hand sides of all columns from one staging of the
+    // Jacobians, one Riccati solve per column, the multipliers of all columns from one staging
+    const Regions r = regions(p, d_work);
+    const long colJ = (long)p->batch * skkt, colV = (long)p->batch * p->in1_len;
+    hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false>), dim3(node_grid(p)),
+                       dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, p->ck, d_model, (const double *)nullptr,
+                       r.inv, r.in0, (const double *)t.J, t.vecs_cols, (long)p->batch, (const int32_t *)d_status,
+                       th, colJ, colV);
+    if ((e = hipGetLastError()) != hipSuccess)
+      return report(e, "sip_kkt_factor_theta(rhs)");
+    for (int col = 0; col < th; ++col) {
+      rc = sip_lqr_solve(p->chain, r.in0, t.vecs_cols + col * colV, t.lsol_cols + col * colV, r.gain, r.lqr, s);
+      if (rc != SIP_LQR_OK)
+        return rc;
+    }
+    hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_recover, s, p->ck, d_model, (const double *)t.J, r.inv,
+                       (const double *)t.lsol_cols, t.KJ, (const int32_t *)d_status, (long)p->batch, th, colJ, colV,
+                       colJ);
+    if ((e = hipGetLastError()) != hipSuccess)
+      return report(e, "sip_kkt_factor_theta(recover)");
+  } else {
+    for (int col = 0; col < th; ++col) { // K^-1 J_theta, one column per launch (helpers.cpp:387)
+      rc = sip_kkt_solve(p, d_model, t.J + (size_t)col * p->batch * skkt, t.KJ + (size_t)col * p->batch * skkt,
+                         d_work, d_status, stream);
+      if (rc != SIP_LQR_OK)
+        return rc;
+    }
   }
   if (th <= 8)
     hipLaunchKernelGGL(sipamd::kkt::theta_schur_small_kernel<8>, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
