@@ -174,3 +174,15 @@ def test_fp32_c4_shape_kkt_residual(oracle_lib):
     # and close to the fp64 oracle solution of the same (rounded) problem
     ref_sol, _, _ = oracle_lib.chain_batch(n, m, T, mats.double().cpu().numpy(), vecs.double().cpu().numpy())
     assert _rel(sol.double().cpu().numpy(), ref_sol) < 5e-3
+
+
+def test_randomized_stress_sample():
+    """tools/stress.py (random chain / tree / Newton-KKT shapes against the oracle), a small sample."""
+    import subprocess
+    import sys
+    proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                        "tools", "stress.py"),
+                           "--seed", "11", "--chains", "40", "--trees", "8", "--kkt", "12"],
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert "0 failures" in proc.stdout
