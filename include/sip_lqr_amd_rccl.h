@@ -1,0 +1,52 @@
+/*
+ * sip_lqr_amd_rccl.h -- multi-GPU side of the batched LQR path: the exchange of
+ * the feedback gains (K, k) between the GPUs of one node over RCCL / xGMI.
+ *
+ * Problem instances are independent (no shared state between the reference's
+ * LQR / Workspace pairs, lqr.hpp:189-199), so the batch is block-partitioned
+ * over the GPUs with no data-path collective; the one exchange step is the
+ * all-gather of every shard's gains.  The reference
+ * has no multi-GPU code; this header completes the C ABI of sip_lqr_amd.h for
+ * callers that are not torch programs.  It lives in its own library
+ * (libsip_lqr_amd_rccl.so, links librccl) so that libsip_lqr_amd.so itself
+ * carries no communication dependency.
+ *
+ * Two process models:
+ *   - one process per GPU (what bench.py does through torch.distributed): the
+ *     caller owns its ncclComm_t (ncclCommInitRank) and calls
+ *     sip_lqr_all_gather_gains();
+ *   - one process driving several GPUs: sip_lqr_group_create() builds the
+ *     communicators (ncclCommInitAll) and sip_lqr_group_all_gather_gains()
+ *     issues the collective for all of them inside one ncclGroupStart/End.
+ */
+#ifndef SIP_LQR_AMD_RCCL_H
+#define SIP_LQR_AMD_RCCL_H
+
+#include "sip_lqr_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sip_lqr_group sip_lqr_group;
+
+/* devices[i]: HIP device ordinal of rank i; ndev >= 1. */
+int sip_lqr_group_create(int ndev, const int *devices, sip_lqr_group **group);
+void sip_lqr_group_destroy(sip_lqr_group *group);
+int sip_lqr_group_size(const sip_lqr_group *group);
+
+/* Rank i contributes d_gains[i] (sip_lqr_gains_bytes(plans[i]) bytes, the same on every rank) and
+ * receives the shards of all ranks, rank-major, in d_all_gains[i] (ndev times that); the copy for
+ * rank i is enqueued on streams[i] (hipStream_t), behind the sweep that produced the gains. */
+int sip_lqr_group_all_gather_gains(sip_lqr_group *group, const sip_lqr_plan *const *plans,
+                                   const void *const *d_gains, void *const *d_all_gains,
+                                   void *const *streams);
+
+/* One process per GPU: `nccl_comm` is the caller's ncclComm_t. */
+int sip_lqr_all_gather_gains(const sip_lqr_plan *plan, void *nccl_comm, const void *d_gains,
+                             void *d_all_gains, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+// test_group.cpp -- include/sip_lqr_amd_rccl.h on the devices that are present (one on the test box):
+// a sweep per device, then the all-gather of the gains through sip_lqr_group_all_gather_gains and,
+// with the same communicator handed over as the caller's, sip_lqr_all_gather_gains.
+#include "sip_lqr_amd_rccl.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static int g_failures = 0;
+#define CHECK(cond)                                                         \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      ++g_failures;                                                         \
+      std::printf("  CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+    }                                                                       \
+  } while (0)
+
+int main() {
+  int ndev = 0;
+  CHECK(hipGetDeviceCount(&ndev) == hipSuccess && ndev >= 1);
+  if (ndev > 4)
+    ndev = 4;
+  std::vector<int> devices(ndev);
+  for (int i = 0; i < ndev; ++i)
+    devices[i] = i;
+  sip_lqr_group *group = nullptr;
+  CHECK(sip_lqr_group_create(ndev, devices.data(), &group) == SIP_LQR_OK && group != nullptr);
+  CHECK(sip_lqr_group_size(group) == ndev);
+  sip_lqr_group *none = nullptr;
+  CHECK(sip_lqr_group_create(0, devices.data(), &none) == SIP_LQR_ERR_INVALID_ARGUMENT && none == nullptr);
+
+  const int T = 6, n = 4, m = 2;
+  const int64_t batch = 5;
+  std::vector<sip_lqr_plan *> plans(ndev, nullptr);
+  std::vector<void *> mats(ndev), vecs(ndev), sol(ndev), gains(ndev), all(ndev), ws(ndev), streams(ndev, nullptr);
+  std::vector<int32_t *> status(ndev);
+  std::vector<std::vector<double>> host_gains(ndev);
+  for (int r = 0; r < ndev; ++r) {
+    CHECK(hipSetDevice(r) == hipSuccess);
+    CHECK(sip_lqr_plan_create(SIP_LQR_F64, batch, T, n, m, r, &plans[r]) == SIP_LQR_OK);
+    const size_t mb = sip_lqr_mats_bytes(plans[r]), vb = sip_lqr_vecs_bytes(plans[r]), gb = sip_lqr_gains_bytes(plans[r]);
+    // the default LQRProblem of the reference's tests (lqr_test.cpp:45-75), scaled per rank
+    std::vector<double> hm(mb / 8, 0.0), hv(vb / 8, 0.0);
+    const size_t stage = (size_t)(n * n + n) + (size_t)(n * n + 2 * n * m + m * m);
+    for (int64_t p = 0; p < batch; ++p) {
+      double *pm = hm.data() + p * (mb / 8 / batch);
+      double *pv = hv.data() + p * (vb / 8 / batch);
+      for (int i = 0; i <= T; ++i) {
+        double *blk = pm + i * stage;
+        for (int d = 0; d < n; ++d)
+          blk[d + n * d] = 1.0 + 0.1 * r + 0.01 * p, blk[n * n + d] = 1.0; // Q, delta
+        if (i < T) {
+          double *e = blk + n * n + n;
+          for (int d = 0; d < n; ++d)
+            e[d + n * d] = 1.0; // A = I
+          for (int k = 0; k < n * m; ++k)
+            e[n * n + k] = 1.0; // B = ones
+          for (int d = 0; d < m; ++d)
+            e[n * n + 2 * n * m + d + m * d] = 1.0; // R = I
+        }
+        pv[i * (2 * n + m) + n] = 1.0; // c[0] = 1
+      }
+    }
+    CHECK(hipMalloc(&mats[r], mb) == hipSuccess && hipMalloc(&vecs[r], vb) == hipSuccess);
+    CHECK(hipMalloc(&sol[r], vb) == hipSuccess && hipMalloc(&gains[r], gb) == hipSuccess);
+    CHECK(hipMalloc(&all[r], gb * ndev) == hipSuccess && hipMalloc(&ws[r], sip_lqr_workspace_bytes(plans[r])) == hipSuccess);
+    CHECK(hipMalloc((void **)&status[r], sip_lqr_status_bytes(plans[r])) == hipSuccess);
+    CHECK(hipMemcpy(mats[r], hm.data(), mb, hipMemcpyHostToDevice) == hipSuccess);
+    CHECK(hipMemcpy(vecs[r], hv.data(), vb, hipMemcpyHostToDevice) == hipSuccess);
+    CHECK(sip_lqr_factor_solve(plans[r], mats[r], vecs[r], sol[r], gains[r], status[r], ws[r], nullptr) == SIP_LQR_OK);
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    host_gains[r].resize(gb / 8);
+    CHECK(hipMemcpy(host_gains[r].data(), gains[r], gb, hipMemcpyDeviceToHost) == hipSuccess);
+    std::vector<int32_t> st(batch);
+    CHECK(hipMemcpy(st.data(), status[r], batch * 4, hipMemcpyDeviceToHost) == hipSuccess);
+    for (int32_t s : st)
+      CHECK(s == SIP_LQR_SUCCESS);
+  }
+  CHECK(sip_lqr_group_all_gather_gains(group, plans.data(), gains.data(), all.data(), streams.data()) == SIP_LQR_OK);
+  const size_t gl = host_gains[0].size();
+  for (int r = 0; r < ndev; ++r) {
+    CHECK(hipSetDevice(r) == hipSuccess && hipDeviceSynchronize() == hipSuccess);
+    std::vector<double> got(gl * ndev);
+    CHECK(hipMemcpy(got.data(), all[r], gl * ndev * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    for (int q = 0; q < ndev; ++q)
+      CHECK(std::memcmp(got.data() + q * gl, host_gains[q].data(), gl * 8) == 0);
+    CHECK(host_gains[r][0] != 0.0);
+  }
+  std::printf("group of %d device(s): all-gather of %zu gains per rank ok\n", ndev, gl);
+  for (int r = 0; r < ndev; ++r)
+    sip_lqr_plan_destroy(plans[r]);
+  sip_lqr_group_destroy(group);
+  std::printf("%d failures\n", g_failures);
+  return g_failures == 0 ? 0 : 1;
+}

@@ -19,9 +19,13 @@ def lib():
     return load_library()
 
 
-def _declared_functions():
+def _declared_functions(rccl=False):
+    """Entry points declared by the headers of libsip_lqr_amd.so (rccl=False) or of the separate
+    communication library libsip_lqr_amd_rccl.so (rccl=True)."""
     names = set()
     for header in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        if header.endswith("_rccl.h") != rccl:
+            continue
         text = open(header).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names.update(re.findall(r"\b(sip_(?:lqr|kkt)_\w+)\s*\(", text))
@@ -188,3 +192,19 @@ def test_headers_are_plain_c(tmp_path):
                    "int main(void) { return (int)sizeof(sip_lqr_plan *) - (int)sizeof(sip_kkt_plan *); }\n")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                            "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_rccl_library_exports_its_header(lib):
+    """include/sip_lqr_amd_rccl.h lives in its own library (links librccl; never loaded by the
+    Python package, which exchanges through torch.distributed)."""
+    import __graft_entry__ as entry
+    path = entry.build_rccl()
+    declared = _declared_functions(rccl=True)
+    assert declared == {"sip_lqr_group_create", "sip_lqr_group_destroy", "sip_lqr_group_size",
+                        "sip_lqr_group_all_gather_gains", "sip_lqr_all_gather_gains"}
+    out = __import__("subprocess").run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    for name in declared:
+        assert f" T {name}" in out, name
+    package = os.path.join(ROOT, "sip_optimal_control_amd")
+    for f in glob.glob(os.path.join(package, "*.py")):
+        assert "amd_rccl" not in open(f).read()

@@ -34,3 +34,17 @@ def test_cpp_callback_provider_suite():
     assert proc.returncode == 0, proc.stdout[-3000:]
     assert "0 failures" in proc.stdout
     assert proc.stdout.count("[  OK  ]") == 5
+
+
+def test_cpp_group_all_gather():
+    """include/sip_lqr_amd_rccl.h: communicators over the devices present (one here), a sweep per
+    device, all-gather of the gains compared bitwise (tests/cpp/test_group.cpp)."""
+    import __graft_entry__ as entry
+    entry.build_hip()
+    entry.build_rccl()
+    exe = entry.build_group_test()
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(proc.stdout)
+    print(proc.stderr)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert "0 failures" in proc.stdout
