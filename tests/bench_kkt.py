@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Newton-KKT factor+solve throughput on one MI355X: the
+"""TEST / MEASUREMENT INFRASTRUCTURE (times the CPU oracle beside the GPU path and checks against it).
+Newton-KKT factor+solve throughput on one MI355X: the
 loop body of the reference's BM_NewtonKKTFactorSolve
 (benchmarks/newton_kkt_benchmark.cpp:316-324) over a batch of NewtonKKTProblem
 (n, m, T) instances (c = n/2 equality and g = 2m inequality rows per edge and
 on the last node), device-resident.
 
-    python tools/bench_kkt.py [--n 12 --m 4 --T 50 --batch 4096] [--steps 30]
+    python tests/bench_kkt.py [--n 12 --m 4 --T 50 --batch 4096] [--steps 30]
 
 Prints one JSON line: solves/s, the per-launch split (condense+rhs | Riccati |
 recover), the HBM roofline of the whole step (algorithmic bytes = model +

@@ -1,5 +1,12 @@
-import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+"""TEST INFRASTRUCTURE (uses the CPU oracle): accuracy of the fused kernel and of the oracle against
+a dense KKT solve over ranges of the dual regularization delta (run on the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
 from oracle import oracle, dense_kkt
 n, m, T, batch = 12, 4, 50, 8

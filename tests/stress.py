@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Randomized parity stress on the GPU box: many (n, m, T, batch) chain shapes through the fused /
+"""TEST INFRASTRUCTURE (uses the CPU oracle).  Randomized parity stress on the GPU box: many (n, m, T, batch) chain shapes through the fused /
 embedded / general paths (fused and split entry points, injected failures), random trees with
 per-node dimensions, and Newton-KKT problems with random constraint dimensions -- each against the
 CPU oracle.  Prints one line per failure and a summary; exit code 1 on any failure.
 
-    python tools/stress.py [--seed 0] [--chains 120] [--trees 25] [--kkt 40]
+    python tests/stress.py [--seed 0] [--chains 120] [--trees 25] [--kkt 40]
 """
 import argparse
 import os

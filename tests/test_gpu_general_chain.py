@@ -177,11 +177,11 @@ def test_fp32_c4_shape_kkt_residual(oracle_lib):
 
 
 def test_randomized_stress_sample():
-    """tools/stress.py (random chain / tree / Newton-KKT shapes against the oracle), a small sample."""
+    """tests/stress.py (random chain / tree / Newton-KKT shapes against the oracle), a small sample."""
     import subprocess
     import sys
     proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                        "tools", "stress.py"),
+                                                        "tests", "stress.py"),
                            "--seed", "11", "--chains", "40", "--trees", "8", "--kkt", "12"],
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
