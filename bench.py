@@ -36,7 +36,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["kkt"],
+                    help="c1..c4: BASELINE.json configs (Riccati sweeps); kkt: the Newton-KKT step around "
+                         "the sweep (SURVEY.md 8 row f1, NewtonKKTProblem(12, 4, 50), batch 4096)")
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-gather", action="store_true",
                     help="multi-GPU: skip the RCCL all-gather of the gains")
@@ -96,8 +98,81 @@ def cpu_baseline(shape, mats, vecs, seconds):
     }
 
 
+def kkt_cpu_baseline(dims, data, seconds):
+    """The CPU oracle of the Newton-KKT callbacks (oracle/kkt_oracle.c) on a bounded sample."""
+    from oracle.kkt import KKTDims, KKTOracle
+    cores = usable_cores()
+    od = KKTDims(dims["parents"], dims["children"], dims["state_dims"], dims["control_dims"], dims["node_c_dims"],
+                 dims["node_g_dims"], dims["edge_c_dims"], dims["edge_g_dims"])
+    sample = min(data[0].shape[0], max(128, 8 * cores))
+    host = [a[:sample].cpu().numpy() for a in data]
+    o = KKTOracle(od)
+    o.batch(*[a[:4] for a in host], threads=1)
+    t0 = time.perf_counter()
+    ref, _ = o.batch(*host, threads=cores)
+    once = time.perf_counter() - t0
+    reps = max(1, int(seconds / max(once, 1e-6)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o.batch(*host, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": sample * reps / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} problems x {reps} on {cores} threads, oracle/kkt_oracle.c (Eigen-free "
+                      f"restatement of CallbackProvider::factor + solve)"}, ref
+
+
+def kkt_main(args):
+    """One step = CallbackProvider::factor + ::solve (the loop body of BM_NewtonKKTFactorSolve,
+    benchmarks/newton_kkt_benchmark.cpp:316-324) of every problem of the batch, device-resident."""
+    import numpy as np
+    import torch
+    from sip_optimal_control_amd import BatchedNewtonKKT, synthetic
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--workload kkt is a one-GPU measurement")
+    n, m, T = 12, 4, 50
+    batch = args.batch or 4096
+    c, g = n // 2, 2 * m
+    dims = dict(parents=list(range(T)), children=list(range(1, T + 1)), state_dims=[n] * (T + 1),
+                control_dims=[m] * T, node_c_dims=[0] * T + [c], node_g_dims=[0] * T + [g],
+                edge_c_dims=[c] * T, edge_g_dims=[g] * T)
+    torch.cuda.set_device(0)
+    kkt = BatchedNewtonKKT(batch=batch, **dims)
+    data = synthetic.make_newton_kkt_batch(kkt, seed=0, r2_max=1e2, **dims)
+    sol = torch.zeros(batch, kkt.kkt_dim, dtype=torch.float64, device=kkt.device)
+    for _ in range(args.warmup):
+        kkt.factor_solve(*data, sol=sol)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kkt.factor_solve(*data, sol=sol)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = elapsed / args.steps * 1e3
+    alg_bytes = 8 * (kkt.model_len + 2 * kkt.z_dim + kkt.x_dim + kkt.y_dim + 2 * kkt.kkt_dim)
+    achieved = batch * alg_bytes / (ms * 1e-3) / 1e9
+    out = {
+        "metric": "Newton-KKT factor+solves/sec", "value": batch * args.steps / elapsed, "unit": "solves/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"kkt: NewtonKKTProblem(n={n}, m={m}, T={T}), c={c}, g={g}, batch {batch}",
+                   "kernels": kkt.kernel_name, "all_status_success": bool((kkt.status == 0).all().item())},
+        # whole step (3 launches + the Riccati sweep): algorithmic bytes = model + w, r1, r2, r3, b read
+        # once + sol written once; PMC traffic of the step in profiles/r01_kkt/traffic_end.md
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": 4.802e9 if batch == 4096 else None,
+                     "algorithmic_bytes_per_launch": alg_bytes * batch},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"], ref = kkt_cpu_baseline(dims, data, args.cpu_seconds)
+        got = sol[:ref.shape[0]].cpu().numpy()
+        out["max_rel_err_vs_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.workload == "kkt":
+        return kkt_main(args)
     import torch
     import torch.distributed as dist
     from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
