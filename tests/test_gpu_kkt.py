@@ -329,3 +329,43 @@ def test_full_size_properties():
     assert st.tolist() == [0, 0, 0]
     got = sol[pick].cpu().numpy()
     assert (np.abs(got - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= REL
+
+
+def test_step_is_hip_graph_capturable():
+    """The fused Newton-KKT step and the Riccati sweep only enqueue work on the caller's stream (no
+    host synchronisation, no host-side allocation), so a Newton loop can be captured once in a
+    hipGraph and replayed: new right-hand sides are picked up from the captured buffers.  Capture
+    and replay on an explicit (non-default) stream."""
+    from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
+    dims = rk.newton_kkt_dims(12, 4, 20)
+    batch = 16
+    arrays = rk.newton_kkt_problem(dims, seed=77, batch=batch, r2_max=1e2)
+    kkt = _make(dims, batch)
+    d = _dev(*arrays)
+    sol = torch.zeros(batch, dims.kkt_dim, dtype=torch.float64, device="cuda")
+    shape = ChainShape(12, 4, 20)
+    mats, vecs = synthetic.make_chain_batch(shape, batch, seed=5, device="cuda:0")
+    lqr = BatchedChainLQR(12, 4, 20, batch)
+    lsol, lgains = lqr.empty_sol(), lqr.empty_gains()
+    oracle_kkt = KKTOracle(dims)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # eager on the side stream (also loads the code objects before capture)
+        kkt.factor_solve(*d, sol=sol)
+        lqr.factor_solve(mats, vecs, lsol, lgains)
+    side.synchronize()
+    eager_lqr = lsol.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        kkt.factor_solve(*d, sol=sol)
+        lqr.factor_solve(mats, vecs, lsol, lgains)
+    with torch.cuda.stream(side):
+        for _ in range(2):  # a new right-hand side in the captured buffer, then replay
+            d[5].copy_(torch.roll(d[5], 1, dims=0))
+            lsol.zero_()
+            graph.replay()
+            side.synchronize()
+            ref, st = oracle_kkt.batch(*[a.cpu().numpy() for a in d])
+            assert st.tolist() == [0] * batch
+            assert (np.abs(sol.cpu().numpy() - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= REL
+            assert torch.equal(lsol, eager_lqr)
