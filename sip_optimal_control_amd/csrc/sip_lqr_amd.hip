@@ -220,41 +220,46 @@ PadDims pad_dims(const sip_lqr_plan *p) {
   return d;
 }
 
-// one thread per scalar of the padded mats of one problem
+// blockIdx.y: problem (strided), blockIdx.x: stage; the threads sweep the padded stage block.
+// Small-integer quotients via float reciprocals (exact for the sizes involved, < 2^12).
+__device__ __forceinline__ int div_small(const int v, const float inv) { return (int)(((float)v + 0.5f) * inv); }
+
 __global__ void __launch_bounds__(256)
 pad_mats_kernel(const PadDims d, const double *__restrict__ mats, double *__restrict__ pm, long batch) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= batch * d.pmats_len)
-    return;
-  const long prob = idx / d.pmats_len;
-  long at = idx - prob * d.pmats_len;
   const int n = d.n, m = d.m, N = d.N, M = d.M;
-  const int pstage = N * N + N + N * N + 2 * N * M + M * M, stage = n * n + n + n * n + 2 * n * m + m * m;
-  const int i = (int)(at / pstage);
-  at -= (long)i * pstage;
-  const double *src = mats + prob * d.mats_len + (long)i * stage;
-  double v;
-  int o = (int)at;
-  if (o < N * N) { // Q: identity on the extra diagonal
-    const int col = o / N, row = o - col * N;
-    v = (row < n && col < n) ? src[row + n * col] : (row == col ? 1.0 : 0.0);
-  } else if ((o -= N * N) < N) { // delta: 1 on the extra states
-    v = o < n ? src[n * n + o] : 1.0;
-  } else if ((o -= N) < N * N) { // A
-    const int col = o / N, row = o - col * N;
-    v = (row < n && col < n) ? src[n * n + n + row + n * col] : 0.0;
-  } else if ((o -= N * N) < N * M) { // B
-    const int col = o / N, row = o - col * N;
-    v = (row < n && col < m) ? src[2 * n * n + n + row + n * col] : 0.0;
-  } else if ((o -= N * M) < N * M) { // M (cross term)
-    const int col = o / N, row = o - col * N;
-    v = (row < n && col < m) ? src[2 * n * n + n + n * m + row + n * col] : 0.0;
-  } else { // R: identity on the extra diagonal
-    o -= N * M;
-    const int col = o / M, row = o - col * M;
-    v = (row < m && col < m) ? src[2 * n * n + n + 2 * n * m + row + m * col] : (row == col ? 1.0 : 0.0);
+  const int i = blockIdx.x; // stage (the terminal stage has only the node block)
+  const int pnode = N * N + N, pstage = pnode + N * N + 2 * N * M + M * M;
+  const int stage = n * n + n + n * n + 2 * n * m + m * m;
+  const int count = i < d.T ? pstage : pnode;
+  const float invN = 1.0f / (float)N, invM = 1.0f / (float)M;
+  for (long prob = blockIdx.y; prob < batch; prob += gridDim.y) {
+    const double *src = mats + prob * d.mats_len + (long)i * stage;
+    double *dst = pm + prob * d.pmats_len + (long)i * pstage;
+    for (int at = threadIdx.x; at < count; at += blockDim.x) {
+      double v;
+      int o = at;
+      if (o < N * N) { // Q: identity on the extra diagonal
+        const int col = div_small(o, invN), row = o - col * N;
+        v = (row < n && col < n) ? src[row + n * col] : (row == col ? 1.0 : 0.0);
+      } else if ((o -= N * N) < N) { // delta: 1 on the extra states
+        v = o < n ? src[n * n + o] : 1.0;
+      } else if ((o -= N) < N * N) { // A
+        const int col = div_small(o, invN), row = o - col * N;
+        v = (row < n && col < n) ? src[n * n + n + row + n * col] : 0.0;
+      } else if ((o -= N * N) < N * M) { // B
+        const int col = div_small(o, invN), row = o - col * N;
+        v = (row < n && col < m) ? src[2 * n * n + n + row + n * col] : 0.0;
+      } else if ((o -= N * M) < N * M) { // M (cross term)
+        const int col = div_small(o, invN), row = o - col * N;
+        v = (row < n && col < m) ? src[2 * n * n + n + n * m + row + n * col] : 0.0;
+      } else { // R: identity on the extra diagonal
+        o -= N * M;
+        const int col = div_small(o, invM), row = o - col * M;
+        v = (row < m && col < m) ? src[2 * n * n + n + 2 * n * m + row + m * col] : (row == col ? 1.0 : 0.0);
+      }
+      dst[at] = v;
+    }
   }
-  pm[idx] = v;
 }
 
 // vecs -> padded vecs (zeros on the extras); PAD = false: padded sol -> sol
@@ -344,8 +349,8 @@ hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, 
   const PadDims d = pad_dims(p);
   const long B = p->batch;
   auto grid = [](long count) { return dim3((unsigned)((count + 255) / 256)); };
-  hipLaunchKernelGGL(pad_mats_kernel, grid(B * d.pmats_len), dim3(256), 0, s, d, (const double *)mats,
-                     (double *)(w + f.pmats), B);
+  hipLaunchKernelGGL(pad_mats_kernel, dim3((unsigned)(d.T + 1), (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, s, d,
+                     (const double *)mats, (double *)(w + f.pmats), B);
   if (vecs != nullptr)
     hipLaunchKernelGGL(pad_vecs_kernel<true>, grid(B * d.pvecs_len), dim3(256), 0, s, d, (const double *)vecs,
                        (double *)(w + f.vecs), B);
