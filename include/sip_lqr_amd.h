@@ -138,20 +138,21 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
 
 /* Replaces: LQR::factor_with_status() alone (lqr.cpp:645-731; called by
  * CallbackProvider::factor, helpers.cpp:368).  Leaves the factor state in
- * d_workspace and the K part of d_gains for later sip_lqr_solve() calls.  For
- * shapes with a fused kernel both split entry points re-run the fused sweep
- * (factor: on a zero right-hand side; solve: with the given one -- refactoring
- * is an order of magnitude cheaper than a second, slower kernel family); other
- * shapes run on the general engine, whose work arena holds the reference's
- * factor state.  sol of a problem whose status != SUCCESS is unspecified. */
+ * d_workspace and the K part of d_gains for later sip_lqr_solve() calls.
+ * Shapes with a fused kernel run its backward sweep alone (fp64: plus the LDL
+ * factors of the G matrices for the vector-only solve mode); other shapes run
+ * on the general engine, whose work arena holds the reference's factor state.
+ * sol of a problem whose status != SUCCESS is unspecified. */
 int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
                    int32_t *d_status, void *d_workspace, void *stream);
 
 /* Replaces: LQR::solve(Output&) alone (lqr.cpp:735-871; called by
  * CallbackProvider::solve, helpers.cpp:826) against the factor state of the
  * last sip_lqr_factor() on the same workspace; may be called repeatedly with
- * new right-hand sides (tests/lqr_test.cpp:431-450).  Fills sol and the k
- * part of gains. */
+ * new right-hand sides (tests/lqr_test.cpp:431-450).  d_gains: the buffer that
+ * sip_lqr_factor() filled (K is read, the k part is written).  Shapes with a
+ * fused fp64 kernel run the affine sweep alone (vectors distributed over the
+ * lanes, no matrix work) followed by the rollout.  Fills sol. */
 int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats,
                   const void *d_vecs, void *d_sol, void *d_gains,
                   void *d_workspace, void *stream);

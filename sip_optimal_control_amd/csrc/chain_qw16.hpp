@@ -312,7 +312,12 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     const double *__restrict__ mats, const double *__restrict__ vecs,
     double *__restrict__ sol, double *__restrict__ gains,
     double *__restrict__ wsp, int *__restrict__ status, const long batch,
-    const int T, const int factor_only SIP_STAMP_ARG) {
+    const int T, const int mode, double *__restrict__ gfac SIP_STAMP_ARG) {
+  // mode 0: fused factor + solve.  mode 1 (split sip_lqr_factor): the backward sweep only, and the
+  // LDL factors of the G matrices go to `gfac` ([problem][stage][Lt (M x M, column per lane) | 1/d
+  // (M)]).  mode 2 (split sip_lqr_solve): no matrix work at all -- the affine sweep of
+  // LQR::solve (lqr.cpp:738-796) runs on distributed vectors against the factor state a mode-1
+  // launch left (S in the spill, K in the gains, the G factors in gfac), then the rollout.
   // N = 16 fills the 16-lane row: no lane is left for the affine column, so the vectors of
   // LQR::solve's backward sweep are kept DISTRIBUTED (lane r holds element r) and every
   // matrix-vector product of the sweep is one dotv block (VDIST mode; direct loads only).
@@ -368,6 +373,18 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   sfor<0, N>([&](auto ii) {
     constexpr int r = decltype(ii)::value;
     E[r] = (c == r) ? 1.0 : 0.0;
+  });
+
+  // Offsets of S(r, k), k = 0..N-1, r = this lane's row, inside a spill slot.
+  int woff[N];
+  sfor<0, N>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    if constexpr (WPACK) {
+      const int lo = k < cm ? k : cm, hi = k < cm ? cm : k; // S(hi, lo)
+      woff[k] = lo * N - (lo * (lo - 1)) / 2 + (hi - lo);
+    } else {
+      woff[k] = cm * N + k; // S symmetric: row r = column r
+    }
   });
 
   int stat = 0;
@@ -566,6 +583,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     rank1x<M, N, true>(G, Hc, Bcol);
     SIP_SEG(3);
     const bool gfail = chol_ldl_dpp<M>(G, rinvG, c); // lqr.cpp:696-701
+    if (mode == 1 && valid) { // G_factor for later solve-only launches (LQR::Workspace::G_factor)
+      double *gf = gfac + (p * (long)T + i) * (M * M + M);
+      if (c < M)
+        sfor<0, M>([&](auto jj) { gf[c * M + decltype(jj)::value] = G[decltype(jj)::value]; });
+      if (c == 0)
+        sfor<0, M>([&](auto jj) { gf[M * M + decltype(jj)::value] = rinvG[decltype(jj)::value]; });
+    }
     SIP_SEG(4);
     if (stat == 0 && gfail)
       stat = 3; // G_FACTORIZATION_FAILURE
@@ -640,6 +664,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     asm volatile("" ::: "memory");
   };
 
+  if (mode != 2) {
   // ---- terminal node (lqr.cpp:651-658 with no child edge) ----------------
   typename C::BM dma_bm;
   typename C::BV dma_bv;
@@ -736,8 +761,78 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   }
   if (valid && c == 0)
     status[p] = stat;
+  } else {
+    // ---- mode 2: the affine sweep alone (lqr.cpp:738-796), vectors distributed over the lanes ----
+    // Node step: t = c - delta o v; h = S D^{-1/2} t (spilled for the rollout); returns
+    // W t = D^{-1/2} (I - S) D^{-1/2} t.
+    auto node_step = [&](const int i, const double v_) {
+      const double dl = pm[(long)i * STG + N * N + cm];
+      const double t_ = pv[(long)i * VSTG + N + cm] - dl * v_;
+      const double sdi = rsqrt_nr(dl);
+      const double phi = sdi * t_;
+      const double *slot = pw + (long)i * WSN;
+      double Srow[N];
+      sfor<0, N>([&](auto kk) { Srow[decltype(kk)::value] = slot[woff[decltype(kk)::value]]; });
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      dotv<N, true>(acc, phi, Srow);
+      const double sphi = sum4(acc);
+      if (valid && isM)
+        pw[(long)i * WSN + WG + N + c] = sphi;
+      return sdi * (phi - sphi);
+    };
+    double v_ = pv[(long)T * VSTG + cm]; // v_T = q_T
+    double wt = node_step(T, v_);
+    for (int i = T - 1; i >= 0; --i) {
+      const double *em = pm + (long)i * STG + L::NODE;
+      const double *gi = pg + (long)i * L::GAIN;
+      const double *gf = gfac + (p * (long)T + i) * (M * M + M);
+      const double gd = v_ + wt; // g = v_c + W t  (lqr.cpp:780-781)
+      if (valid && isM)
+        pw[(long)(i + 1) * WSN + WG + c] = gd;
+      double Bcol[N], Acol[N], Kc[M], hf[M], kf[M], Lf[M][M], rinv[M];
+      sfor<0, N>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        Bcol[k] = em[N * N + cu * N + k];
+        Acol[k] = em[cm * N + k];
+      });
+      sfor<0, M>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        Kc[j] = gi[cm * M + j];
+        rinv[j] = gf[M * M + j];
+        sfor<0, j>([&](auto iv) { Lf[j][decltype(iv)::value] = gf[decltype(iv)::value * M + j]; });
+      });
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      dotv<N, true>(acc, gd, Bcol);
+      const double hd = pv[(long)i * VSTG + L::VNODE + cu] + sum4(acc); // h = r + B^T g  (:783-784)
+      sfor<0, M>([&](auto jj) { hf[decltype(jj)::value] = bcast<decltype(jj)::value>(hd); });
+      sfor<0, M>([&](auto jj) { // k = -G^{-1} h  (:785-791), replicated
+        constexpr int j = decltype(jj)::value;
+        double w = hf[j];
+        sfor<0, j>([&](auto iv) { w = __builtin_fma(-Lf[j][decltype(iv)::value], kf[decltype(iv)::value], w); });
+        kf[j] = w * rinv[j];
+      });
+      sfor_down<M - 1, -1>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        double a = 0.0;
+        sfor<j + 1, M>([&](auto iv) { a = __builtin_fma(Lf[decltype(iv)::value][j], kf[decltype(iv)::value], a); });
+        kf[j] = __builtin_fma(-rinv[j], a, kf[j]);
+      });
+      if (valid && c == 0) {
+        double *gk = pg + (long)i * L::GAIN + N * M;
+        sfor<0, M>([&](auto jj) { gk[decltype(jj)::value] = -kf[decltype(jj)::value]; });
+      }
+      double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+      dotv<N, true>(acc2, gd, Acol);
+      double kh = 0.0; // K^T h with K = -G^{-1} H (the stored gain)
+      sfor<0, M>([&](auto jj) { kh = __builtin_fma(Kc[decltype(jj)::value], hf[decltype(jj)::value], kh); });
+      v_ = pv[(long)i * VSTG + cm] + sum4(acc2) + kh; // v = q + A^T g + K^T h  (:793-794)
+      wt = node_step(i, v_);
+    }
+    if (valid && isM)
+      pw[WG + c] = v_ + wt; // g_0
+  }
 
-  if (factor_only) // split sip_lqr_factor(): gains and statuses only, no rollout
+  if (mode == 1) // split sip_lqr_factor(): gains, G factors and statuses only, no rollout
     return;
   // The rollout reads W / g / K / k written above by other lanes of this
   // wave: workgroup-scope release/acquire (the block is one wavefront).
@@ -745,17 +840,6 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   SIP_STAMP(ts_root);
 
   // ---- forward rollout (lqr.cpp:821-870); lane r < N owns row r ----------
-  // Offsets of W(r, k), k = 0..N-1, inside a [W | g] slot.
-  int woff[N];
-  sfor<0, N>([&](auto kk) {
-    constexpr int k = decltype(kk)::value;
-    if constexpr (WPACK) {
-      const int lo = k < cm ? k : cm, hi = k < cm ? cm : k; // W(hi, lo)
-      woff[k] = lo * N - (lo * (lo - 1)) / 2 + (hi - lo);
-    } else {
-      woff[k] = cm * N + k; // W symmetric: row r = column r
-    }
-  });
 
   typename C::FA dma_fa;
   typename C::FG dma_fg;

@@ -27,7 +27,7 @@ struct sip_lqr_plan {
   // fused factor+solve launcher of a dedicated kernel; nullptr: the general
   // engine (tree_generic.hpp) runs factor then solve
   hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
-                          void *, void *, int32_t *, void *, hipStream_t, int);
+                          void *, void *, int32_t *, void *, hipStream_t, int, void *);
   // General engine on the packed chain layout: serves shapes / dtypes without
   // a dedicated kernel and the split factor / solve entry points.  Tables are
   // laid out at plan creation (host only), uploaded at first use.
@@ -43,6 +43,7 @@ struct sip_lqr_plan {
   // device-side repack before and after the sweep.  SIP_LQR_PAD=0 keeps the general engine.
   bool padded = false;
   int kn = 0, km = 0;
+  bool solve_only = false; // the kernel has the vector-only solve mode (qw16)
   std::string name_storage;
 };
 
@@ -62,7 +63,7 @@ namespace {
 template <int N, int M, bool STAGED, bool WPACK>
 hipError_t launch_qw16(const sip_lqr_plan *pl, const void *mats,
                        const void *vecs, void *sol, void *gains,
-                       int32_t *status, void *ws, hipStream_t stream, int factor_only) {
+                       int32_t *status, void *ws, hipStream_t stream, int mode, void *gfac) {
   using Cfg = sipamd::StagedCfg<N, M, WPACK>;
   const long batch = pl->batch;
   const unsigned blocks = (unsigned)((batch + 3) / 4);
@@ -77,13 +78,14 @@ hipError_t launch_qw16(const sip_lqr_plan *pl, const void *mats,
   hipLaunchKernelGGL((sipamd::chain_factor_solve_qw16<N, M, STAGED, WPACK>),
                      dim3(blocks), dim3(64), lds, stream, (const double *)mats,
                      (const double *)vecs, (double *)sol, (double *)gains,
-                     (double *)ws, (int *)status, batch, pl->T, factor_only SIP_STAMP_PASS);
+                     (double *)ws, (int *)status, batch, pl->T, mode, (double *)gfac SIP_STAMP_PASS);
   return hipGetLastError();
 }
 
 template <int M>
 hipError_t launch_mf32(const sip_lqr_plan *pl, const void *mats, const void *vecs, void *sol, void *gains,
-                       int32_t *status, void *ws, hipStream_t stream, int /*factor_only: full sweep*/) {
+                       int32_t *status, void *ws, hipStream_t stream, int /*mode: always the full sweep*/,
+                       void * /*gfac*/) {
   hipLaunchKernelGGL((sipamd::mf32::chain_factor_solve_mf32<M>), dim3((unsigned)pl->batch), dim3(64), 0,
                      stream, (const float *)mats, (const float *)vecs, (float *)sol, (float *)gains,
                      (float *)ws, (int *)status, (long)pl->batch, pl->T SIP_STAMP_PASS);
@@ -95,7 +97,7 @@ struct KernelEntry {
   const char *name;
   int ws_slot;
   hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
-                          void *, void *, int32_t *, void *, hipStream_t, int);
+                          void *, void *, int32_t *, void *, hipStream_t, int, void *);
 };
 
 // direct: every lane loads its columns from global memory (any N <= 15)
@@ -311,7 +313,7 @@ unpad_gains_kernel(const PadDims d, const double *__restrict__ pg, double *__res
 // Workspace of the fused kernel: spill | scratch vecs (zero rhs of factor) | scratch sol |
 // status copy (for sip_lqr_solve, which has no status argument).
 struct FusedSplit {
-  size_t vecs, sol, status, pmats, pgains, total;
+  size_t vecs, sol, status, gfac, pmats, pgains, total;
 };
 FusedSplit fused_split_layout(const sip_lqr_plan *p) {
   const size_t N = p->kn, M = p->km, T = p->T, B = (size_t)p->batch, sz = scalar_size(p);
@@ -323,19 +325,24 @@ FusedSplit fused_split_layout(const sip_lqr_plan *p) {
   f.vecs = up(spill);
   f.sol = f.vecs + (scratch ? up(vb) : 0);
   f.status = f.sol + (scratch ? up(vb) : 0);
-  f.pmats = f.status + (scratch ? up(B * sizeof(int32_t)) : 0);
+  f.gfac = f.status + (scratch ? up(B * sizeof(int32_t)) : 0); // G factors of the split factor (mode 1)
+  f.pmats = f.gfac + (p->split_on_fused ? up(B * T * (M * M + M) * sz) : 0);
   f.pgains = f.pmats + (p->padded ? up(B * ((T + 1) * (N * N + N) + T * (N * N + 2 * N * M + M * M)) * sz) : 0);
   f.total = f.pgains + (p->padded ? up(B * T * (M * N + M) * sz) : 0);
   return f;
 }
 
-// The fused sweep of a plan, through the embedding when the plan is padded.  vecs == nullptr: zero
-// right-hand side (split factor).  sol / gains == nullptr: not wanted.
+// The sweep of a plan, through the embedding when the plan is padded.  mode 0: fused factor + solve;
+// 1: split factor (vecs == nullptr: zero right-hand side; sol not wanted); 2: split solve against
+// the state a mode-1 call left in `ws` (and, unpadded, in `gains`); kernels without a solve-only
+// mode run the full sweep instead.
 hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, void *sol, void *gains,
-                     int32_t *status, void *ws, hipStream_t s) {
+                     int32_t *status, void *ws, hipStream_t s, int mode) {
   const FusedSplit f = fused_split_layout(p);
   char *w = (char *)ws;
   hipError_t e = hipSuccess;
+  if (mode == 2 && !p->solve_only)
+    mode = 0;
   if (!p->padded) {
     const void *v = vecs;
     if (v == nullptr) {
@@ -343,21 +350,22 @@ hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, 
       v = w + f.vecs;
     }
     if (e == hipSuccess)
-      e = p->launch_fs(p, mats, v, sol ? sol : (void *)(w + f.sol), gains, status, ws, s, vecs == nullptr);
+      e = p->launch_fs(p, mats, v, sol ? sol : (void *)(w + f.sol), gains, status, ws, s, mode, w + f.gfac);
     return e;
   }
   const PadDims d = pad_dims(p);
   const long B = p->batch;
   auto grid = [](long count) { return dim3((unsigned)((count + 255) / 256)); };
-  hipLaunchKernelGGL(pad_mats_kernel, dim3((unsigned)(d.T + 1), (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, s, d,
-                     (const double *)mats, (double *)(w + f.pmats), B);
+  if (mode != 2) // the padded matrices (and gains) of the factor call are still in the workspace
+    hipLaunchKernelGGL(pad_mats_kernel, dim3((unsigned)(d.T + 1), (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, s,
+                       d, (const double *)mats, (double *)(w + f.pmats), B);
   if (vecs != nullptr)
     hipLaunchKernelGGL(pad_vecs_kernel<true>, grid(B * d.pvecs_len), dim3(256), 0, s, d, (const double *)vecs,
                        (double *)(w + f.vecs), B);
   else
     e = hipMemsetAsync(w + f.vecs, 0, f.sol - f.vecs, s);
   if (e == hipSuccess)
-    e = p->launch_fs(p, w + f.pmats, w + f.vecs, w + f.sol, w + f.pgains, status, ws, s, vecs == nullptr);
+    e = p->launch_fs(p, w + f.pmats, w + f.vecs, w + f.sol, w + f.pgains, status, ws, s, mode, w + f.gfac);
   if (e == hipSuccess && sol != nullptr)
     hipLaunchKernelGGL(pad_vecs_kernel<false>, grid(B * d.vecs_len), dim3(256), 0, s, d, (const double *)(w + f.sol),
                        (double *)sol, B);
@@ -416,6 +424,7 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
                                                      : "tree_generic(chain layout)/f64");
   p->ws_slot = k ? k->ws_slot : 0;
   p->launch_fs = k ? k->launch_fs : nullptr;
+  p->solve_only = k != nullptr && k->dtype == SIP_LQR_F64;
   const char *split = std::getenv("SIP_LQR_SPLIT");
   p->split_on_fused = p->launch_fs != nullptr && !(split && std::strcmp(split, "general") == 0);
   init_generic(p);
@@ -577,7 +586,7 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
   if (plan->launch_fs != nullptr)
-    return report(run_fused(plan, d_mats, d_vecs, d_sol, d_gains, d_status, d_workspace, s),
+    return report(run_fused(plan, d_mats, d_vecs, d_sol, d_gains, d_status, d_workspace, s, 0),
                   "sip_lqr_factor_solve");
   // no dedicated kernel for this shape / dtype: general engine, two launches
   hipError_t e = ensure_generic(plan);
@@ -602,7 +611,7 @@ int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
   if (plan->split_on_fused) { // fused sweep on a zero right-hand side: K, statuses
     const FusedSplit f = fused_split_layout(plan);
     char *w = (char *)d_workspace;
-    hipError_t e = run_fused(plan, d_mats, nullptr, nullptr, d_gains, d_status, d_workspace, s);
+    hipError_t e = run_fused(plan, d_mats, nullptr, nullptr, d_gains, d_status, d_workspace, s, 1);
     if (e == hipSuccess)
       e = hipMemcpyAsync(w + f.status, d_status, (size_t)plan->batch * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
     return report(e, "sip_lqr_factor(fused)");
@@ -626,7 +635,7 @@ int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats, const void *d_ve
   if (plan->split_on_fused) { // the fused sweep again, now with the right-hand side
     const FusedSplit f = fused_split_layout(plan);
     return report(run_fused(plan, d_mats, d_vecs, d_sol, d_gains, (int32_t *)((char *)d_workspace + f.status),
-                            d_workspace, s),
+                            d_workspace, s, 2),
                   "sip_lqr_solve(fused)");
   }
   hipError_t e = ensure_generic(plan);

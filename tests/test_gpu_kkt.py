@@ -210,8 +210,9 @@ def test_condensation_variants_agree_bitwise(monkeypatch):
         kkt.factor(*d[:5])
         sols[variant] = (sol.clone(), kkt.solve(d[0], d[5]).clone())
     assert torch.equal(sols["tables"][0], sols["direct"][0]) and torch.equal(sols["tables"][1], sols["direct"][1])
-    for pair in (sols[""], sols["tables"]):
-        assert torch.equal(pair[0], pair[1])  # fused and split entry points
+    for pair in (sols[""], sols["tables"]):  # fused and split entry points (the split solve is the
+        tol = 1e-12 * pair[0].abs().amax(dim=1, keepdim=True)  # vector-only sweep: same to rounding)
+        assert bool(((pair[0] - pair[1]).abs() <= tol).all())
     # the chain kernels sum the rank updates on the matrix pipe: same to rounding
     scale = sols["tables"][0].abs().amax(dim=1, keepdim=True)
     assert float(((sols[""][0] - sols["tables"][0]).abs() / scale).max()) <= 1e-12
