@@ -50,6 +50,16 @@ def test_flags_vcmpx_exec_write():
     assert len(_probs(f"\tv_cmpx_gt_u32_e32 v1, v2\n\ts_nop 1\n\t{DPP}")) == 1
 
 
+def test_flags_trans_result_used_by_next_valu():
+    """gfx940+: a TRANS result (v_rcp_f64 ...) needs one wait state before a VALU reads it."""
+    rcp = "\tv_rcp_f64_e32 v[2:3], v[6:7]"
+    assert len(_probs(f"{rcp}\n\tv_fma_f64 v[8:9], v[2:3], v[6:7], v[10:11]")) == 1
+    assert len(_probs(f"{rcp}\n\tv_fmac_f64_e32 v[2:3], v[6:7], v[10:11]")) == 1     # accumulator read
+    assert _probs(f"{rcp}\n\ts_nop 0\n\tv_fma_f64 v[8:9], v[2:3], v[6:7], v[10:11]") == []
+    assert _probs(f"{rcp}\n\tv_mul_f64 v[20:21], v[6:7], v[6:7]\n\tv_fma_f64 v[8:9], v[2:3], v[6:7], v[10:11]") == []
+    assert _probs(f"{rcp}\n\tv_fma_f64 v[8:9], v[12:13], v[6:7], v[10:11]") == []     # unrelated registers
+
+
 def test_shipped_kernels_are_hazard_free():
     """Rebuild the device assembly and check every kernel of the library."""
     import subprocess

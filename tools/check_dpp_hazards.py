@@ -9,7 +9,9 @@ VALU write of EXEC and any DPP instruction.  This script walks the `.s` of the
 device code (hipcc -save-temps) and reports every DPP read whose source
 register was written by a VALU instruction fewer than 2 wait states earlier on
 ANY path (fall-through or branch), and every v_cmpx within 5 wait states of a
-DPP instruction.
+DPP instruction.  It also checks the gfx940+ TRANS forwarding hazard that an asm block with a
+transcendental in it has to respect by itself: one wait state between a TRANS instruction (v_rcp,
+v_rsq, v_sqrt, v_exp, v_log, v_sin, v_cos) and a non-TRANS VALU instruction that reads its result.
 
 usage: check_dpp_hazards.py file.s [kernel-name-substring ...]; exit code 1 on a hazard.
 """
@@ -77,6 +79,21 @@ def dpp_source(item):
     return regs(src0)
 
 
+TRANS_PREFIX = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
+
+
+def valu_read(item):
+    mnem, ops = item[1], item[2]
+    if not mnem.startswith(VALU_PREFIX):
+        return set()
+    out = set()
+    for o in ops[1:]:
+        out |= regs(o.split()[0]) if o.split() else set()
+    if "fmac" in mnem or "_mac_" in mnem:  # accumulator is read too
+        out |= regs(ops[0])
+    return out
+
+
 def check(items, name):
     # control-flow: index of labels, predecessors by branch
     label_at = {it[1]: i for i, it in enumerate(items) if it[0] == "label"}
@@ -115,6 +132,11 @@ def check(items, name):
     for i, it in enumerate(items):
         if it[0] != "ins":
             continue
+        if it[1].startswith(VALU_PREFIX) and not it[1].startswith(TRANS_PREFIX):
+            reads = valu_read(it)
+            for prev, ws in preceding(i, 1):
+                if prev[1].startswith(TRANS_PREFIX) and ws < 1 and (valu_written(prev) & reads):
+                    problems.append((name, prev[3], it[3], ws, "TRANS result -> VALU read needs 1 wait state"))
         src = dpp_source(it)
         if src is None:
             continue
