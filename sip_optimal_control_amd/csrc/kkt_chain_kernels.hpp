@@ -64,7 +64,11 @@ __device__ __forceinline__ double dot_seq(double acc, const double *a, const dou
 
 // HBM -> LDS copy of `len` doubles by one wavefront.  All the loads of a pass
 // are issued before the first LDS store (a plain copy loop waits for each
-// load in turn: one HBM round trip per 1 KB).
+// load in turn: one HBM round trip per 1 KB).  The loads are unconditional
+// (index clamped to the last piece) and only the LDS stores are predicated:
+// predicated loads compile to a branch per load and zero-initialised
+// destination registers, whose writes make the compiler drain every load that
+// is still in flight (the caller's early reads) before the copy starts.
 __device__ __forceinline__ void stage_copy2(double *dst, const double *__restrict__ src, int len, int tid) {
   constexpr int U = 8;
   // 16-byte pieces when both ends allow it (len even, both 16-byte aligned)
@@ -72,12 +76,25 @@ __device__ __forceinline__ void stage_copy2(double *dst, const double *__restric
     const d2_t *s2 = (const d2_t *)src;
     d2_t *d2 = (d2_t *)dst;
     const int len2 = len >> 1;
+    if (len2 <= U * TPB) { // one pass, straight-line: a loop's back edge makes the compiler wait for
+                           // loads of "the previous iteration", i.e. for everything in flight
+      if (len2 > 0) {
+        d2_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          v[u] = s2[min(tid + u * TPB, len2 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (tid + u * TPB < len2)
+            d2[tid + u * TPB] = v[u];
+      }
+      return;
+    }
     for (int base = tid; base < len2; base += U * TPB) {
       d2_t v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (base + u * TPB < len2)
-          v[u] = s2[base + u * TPB];
+        v[u] = s2[min(base + u * TPB, len2 - 1)];
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (base + u * TPB < len2)
@@ -88,8 +105,7 @@ __device__ __forceinline__ void stage_copy2(double *dst, const double *__restric
       double v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (base + u * TPB < len)
-          v[u] = src[base + u * TPB];
+        v[u] = src[min(base + u * TPB, len - 1)];
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (base + u * TPB < len)
@@ -98,89 +114,167 @@ __device__ __forceinline__ void stage_copy2(double *dst, const double *__restric
   }
 }
 
+// Two HBM -> LDS copies with the loads of BOTH in flight before the first LDS store (two calls of
+// stage_copy2 would cost two HBM round trips).  Falls back to consecutive copies when a range is
+// unaligned or longer than 4 KB.
+__device__ __forceinline__ void stage_copy_pair(double *d0, const double *__restrict__ s0, int l0, double *d1,
+                                                const double *__restrict__ s1, int l1, int tid) {
+  constexpr int U = 4;
+  auto vec_ok = [](const double *s, const double *d, int l) {
+    return ((l | (int)((uintptr_t)s >> 3) | (int)((uintptr_t)d >> 3)) & 1) == 0 && (l >> 1) <= U * TPB;
+  };
+  if (l0 > 0 && l1 > 0 && vec_ok(s0, d0, l0) && vec_ok(s1, d1, l1)) {
+    const d2_t *a2 = (const d2_t *)s0, *b2 = (const d2_t *)s1;
+    d2_t *da = (d2_t *)d0, *db = (d2_t *)d1;
+    const int n0 = l0 >> 1, n1 = l1 >> 1;
+    d2_t va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      va[u] = a2[min(tid + u * TPB, n0 - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      vb[u] = b2[min(tid + u * TPB, n1 - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (tid + u * TPB < n0)
+        da[tid + u * TPB] = va[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (tid + u * TPB < n1)
+        db[tid + u * TPB] = vb[u];
+  } else {
+    stage_copy2(d0, s0, l0, tid);
+    stage_copy2(d1, s1, l1, tid);
+  }
+}
+
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// WITH_RHS: also q_mod / r_mod / c_mod from b.  MATS = false (the split solve path): ONLY those --
-// the Jacobians of the stage are staged, no Q_mod / M_mod / R_mod / A / B work, `status` problems
-// with a failed factorization are skipped.
-template <bool WITH_RHS, bool MATS = true>
-__global__ void __launch_bounds__(TPB)
-condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, const double *__restrict__ r1_all,
-                      const double *__restrict__ inv_all, double *__restrict__ mats_all,
-                      const double *__restrict__ b_all, double *__restrict__ vecs_all, long batch,
-                      const int32_t *__restrict__ status = nullptr, const int ncols = 1,
-                      const long b_col_stride = 0, const long vecs_col_stride = 0) {
-  // ncols > 1 (the columns of J_theta, helpers.cpp:414-747): column j's right-hand side is
-  // b_all + j * b_col_stride, its q_mod / r_mod / c_mod go to vecs_all + j * vecs_col_stride; the
-  // Jacobians of the stage are staged once for all columns.
-  static_assert(MATS || WITH_RHS, "nothing to do");
-  extern __shared__ double sm[];
-  const int n = ck.n, m = ck.m, T = ck.T;
-  double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows;
-  const long p = blockIdx.x / (T + 1);
-  const int i = blockIdx.x - (unsigned)(p * (T + 1));
-  if (p >= batch || (!MATS && status != nullptr && status[p] != 0))
-    return;
-  const int tid = threadIdx.x;
-  const bool last = i == T;
-  const int c = last ? ck.cT : ck.cn, g = last ? ck.gT : ck.gn;
-  const int ce = last ? 0 : ck.ce, ge = last ? 0 : ck.ge;
-  const int nn = n * n, nm = n * m;
-  const int node_len = nn + (c + g) * n;
-  const long kkt = (long)ck.x_dim + ck.y_dim + ck.z_dim;
-  const double *item = model_all + p * ck.model_len + (long)i * (ck.node_len + ck.edge_len);
-  const double *r1 = r1_all + p * ck.x_dim + i * (n + m);
-  const double *yinv = inv_all + p * ((long)ck.y_dim + ck.z_dim), *zinv = yinv + ck.y_dim;
-  // flattened orderings (types.cpp:24-64) of a uniform chain
-  const int y_dyn = i * (n + ck.cn), y_nc = y_dyn + n, y_ec = T * (n + ck.cn) + n + ck.cT + i * ck.ce;
-  const int z_n = i * ck.gn, z_e = T * ck.gn + ck.gT + i * ck.ge;
-  const double *b = WITH_RHS ? b_all + p * kkt : nullptr;
-  const double *b_y = WITH_RHS ? b + ck.x_dim : nullptr, *b_z = WITH_RHS ? b_y + ck.y_dim : nullptr;
-  double *mats = mats_all + p * ck.mats_len + (long)i * ck.mats_stage;
-  double *vecs = WITH_RHS ? vecs_all + p * ck.vecs_len + (long)i * ck.vecs_stage : nullptr;
+// ---- condensation of one stage (node i + edge i of problem p), in pieces so that the one-stage
+// kernel and the software-pipelined kernel below share them ----
+struct CondenseItem {
+  long p;
+  int i;
+  bool last;
+  int c, g, ce, ge, nrows, node_len, edge_len;
+  int y_dyn, y_nc, y_ec, z_n, z_e; // flattened orderings (types.cpp:24-64) of a uniform chain
+  const double *item, *r1, *yinv, *zinv, *b, *b_y, *b_z;
+  double *mats, *vecs;
+};
 
-  // whole stage (node item + edge item are adjacent in the model arena) -> LDS,
-  // and the weights 1/r2, 1/(w+r3) of its constraint rows: [node c | node g | edge c | edge g]
-  const int edge_len = last ? 0 : ck.edge_len;
+template <bool WITH_RHS>
+__device__ __forceinline__ CondenseItem condense_item(const ChainKkt &ck, const long p, const int i,
+                                                      const double *model_all, const double *r1_all,
+                                                      const double *inv_all, double *mats_all, const double *b_all,
+                                                      double *vecs_all) {
+  CondenseItem it;
+  const int n = ck.n, m = ck.m, T = ck.T;
+  it.p = p, it.i = i, it.last = i == T;
+  it.c = it.last ? ck.cT : ck.cn, it.g = it.last ? ck.gT : ck.gn;
+  it.ce = it.last ? 0 : ck.ce, it.ge = it.last ? 0 : ck.ge;
+  it.nrows = it.c + it.g + it.ce + it.ge;
+  it.node_len = n * n + (it.c + it.g) * n, it.edge_len = it.last ? 0 : ck.edge_len;
+  const long kkt = (long)ck.x_dim + ck.y_dim + ck.z_dim;
+  it.item = model_all + p * ck.model_len + (long)i * (ck.node_len + ck.edge_len);
+  it.r1 = r1_all != nullptr ? r1_all + p * ck.x_dim + i * (n + m) : nullptr;
+  it.yinv = inv_all + p * ((long)ck.y_dim + ck.z_dim), it.zinv = it.yinv + ck.y_dim;
+  it.y_dyn = i * (n + ck.cn), it.y_nc = it.y_dyn + n, it.y_ec = T * (n + ck.cn) + n + ck.cT + i * ck.ce;
+  it.z_n = i * ck.gn, it.z_e = T * ck.gn + ck.gT + i * ck.ge;
+  it.b = WITH_RHS ? b_all + p * kkt : nullptr;
+  it.b_y = WITH_RHS ? it.b + ck.x_dim : nullptr, it.b_z = WITH_RHS ? it.b_y + ck.y_dim : nullptr;
+  it.mats = mats_all + p * ck.mats_len + (long)i * ck.mats_stage;
+  it.vecs = WITH_RHS ? vecs_all + p * ck.vecs_len + (long)i * ck.vecs_stage : nullptr;
+  return it;
+}
+
+// entry of the right-hand side / weight 1/r2, 1/(w+r3) that belongs to constraint row k of the
+// stage; rows are ordered [node c | node g | edge c | edge g]
+__device__ __forceinline__ double condense_rhs_row(const CondenseItem &it, const int k, const double *by,
+                                                   const double *bz) {
+  if (k < it.c)
+    return by[it.y_nc + k];
+  if (k < it.c + it.g)
+    return bz[it.z_n + (k - it.c)];
+  if (k < it.c + it.g + it.ce)
+    return by[it.y_ec + (k - it.c - it.g)];
+  return bz[it.z_e + (k - it.c - it.g - it.ce)];
+}
+__device__ __forceinline__ double condense_weight_row(const CondenseItem &it, const int k) {
+  if (k < it.c)
+    return it.yinv[it.y_nc + k];
+  if (k < it.c + it.g)
+    return it.zinv[it.z_n + (k - it.c)];
+  if (k < it.c + it.g + it.ce)
+    return it.yinv[it.y_ec + (k - it.c - it.g)];
+  return it.zinv[it.z_e + (k - it.c - it.g - it.ce)];
+}
+
+// The small reads of a stage (weight and right-hand side of the lane's constraint row, r1, dyn_r2,
+// the lane's entries of b), held in registers from the moment they are issued.
+struct CondensePre {
+  double w, b, q, dy, d, r1;
+};
+
+template <bool WITH_RHS, bool MATS>
+__device__ __forceinline__ void condense_prefetch(const ChainKkt &ck, const CondenseItem &it, const int tid,
+                                                  CondensePre &pre) {
+  const int n = ck.n, m = ck.m;
+  pre.w = pre.b = pre.q = pre.dy = pre.d = pre.r1 = 0.0;
+  if (tid < it.nrows) {
+    pre.w = condense_weight_row(it, tid);
+    if (WITH_RHS)
+      pre.b = condense_rhs_row(it, tid, it.b_y, it.b_z);
+  }
   if (MATS) {
-    stage_copy2(buf, item, node_len + edge_len, tid);
-  } else { // the Jacobian tails only, at their usual places in the image
-    stage_copy2(buf + nn, item + nn, (c + g) * n, tid);
-    if (!last) {
-      const int o_tail = node_len + 2 * nn + 2 * nm + m * m;
-      stage_copy2(buf + o_tail, item + o_tail, (ce + ge) * (n + m), tid);
+    if (tid < n)
+      pre.d = it.yinv[it.y_dyn + tid];
+    if (tid < (it.last ? n : n + m))
+      pre.r1 = it.r1[tid];
+  }
+  if (WITH_RHS) {
+    if (tid < n) {
+      pre.q = it.b[it.i * (n + m) + tid];
+      pre.dy = it.b_y[it.y_dyn + tid];
+    } else if (!it.last && tid >= 32 && tid - 32 < m) {
+      pre.q = it.b[it.i * (n + m) + n + (tid - 32)];
     }
   }
-  const int nrows = c + g + ce + ge;
-  // entry of the right-hand side that belongs to constraint row k of this stage
-  auto rhs_row = [&](const int k, const double *by, const double *bz) {
-    if (k < c)
-      return by[y_nc + k];
-    if (k < c + g)
-      return bz[z_n + (k - c)];
-    if (k < c + g + ce)
-      return by[y_ec + (k - c - g)];
-    return bz[z_e + (k - c - g - ce)];
-  };
-  for (int k = tid; k < nrows; k += TPB) {
-    double wk;
-    if (k < c)
-      wk = yinv[y_nc + k];
-    else if (k < c + g)
-      wk = zinv[z_n + (k - c)];
-    else if (k < c + g + ce)
-      wk = yinv[y_ec + (k - c - g)];
-    else
-      wk = zinv[z_e + (k - c - g - ce)];
+}
+
+// the LDS side of the small reads: weights | weighted right-hand side rows | r1 of the stage
+template <bool WITH_RHS, bool MATS>
+__device__ __forceinline__ void condense_commit(const ChainKkt &ck, const CondenseItem &it, const int tid,
+                                                const CondensePre &pre, double *wl, double *wr, double *r1s) {
+  if (tid < it.nrows) {
+    wl[tid] = pre.w;
+    if (WITH_RHS)
+      wr[tid] = pre.w * pre.b; // weights(constraint) * rhs(constraint), helpers.cpp:143
+  }
+  for (int k = tid + TPB; k < it.nrows; k += TPB) { // more than 64 constraint rows in a stage
+    const double wk = condense_weight_row(it, k);
     wl[k] = wk;
     if (WITH_RHS)
-      wr[k] = wk * rhs_row(k, b_y, b_z); // weights(constraint) * rhs(constraint), helpers.cpp:143
+      wr[k] = wk * condense_rhs_row(it, k, it.b_y, it.b_z);
   }
+  if (MATS && tid < (it.last ? ck.n : ck.n + ck.m))
+    r1s[tid] = pre.r1;
+}
+
+// Everything after the stage is in LDS (`buf`: the stage's model image; for MATS = false only its
+// Jacobians, at their usual places).
+template <bool WITH_RHS, bool MATS>
+__device__ __forceinline__ void condense_compute(const ChainKkt &ck, const CondenseItem &it, const int tid,
+                                                 const CondensePre &pre, const double *buf, const double *wl,
+                                                 double *wr, const double *r1s, const int ncols_rhs,
+                                                 const long b_col_stride, const long vecs_col_stride) {
+  const int n = ck.n, m = ck.m, nn = n * n, nm = n * m;
+  const bool last = it.last;
+  const int c = it.c, g = it.g, ce = it.ce, ge = it.ge;
   const double *Jc = buf + nn, *Jg = Jc + c * n;
-  const double *eb = buf + node_len; // edge item
+  const double *eb = buf + it.node_len; // edge item
   const int o_m = nn, o_r = o_m + nm, o_a = o_r + m * m, o_b = o_a + nn, o_j = o_b + nm;
   const double *Jxc = eb + o_j, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
-  __syncthreads();
+  double *mats = it.mats;
 
   if (MATS)
   // ---- Q_mod, M_mod, R_mod (helpers.cpp:299-361) ----
@@ -218,7 +312,7 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
             if (J <= I) { // Q_mod, lower, mirrored (:310-318, 336-339, 357-361)
               double v = buf[I + n * J];
               if (I == J)
-                v += r1[I];
+                v += r1s[I];
               if (!last)
                 v += eb[I + n * J];
               v += t;
@@ -233,7 +327,7 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
               const int uj = J - n;
               double v = eb[o_r + u + m * uj];
               if (u == uj)
-                v += r1[n + u];
+                v += r1s[n + u];
               v += t;
               Rm[u + m * uj] = v;
               Rm[uj + m * u] = v;
@@ -243,7 +337,7 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
       }
     }
     if (tid < n)
-      mats[nn + tid] = yinv[y_dyn + tid]; // dyn_r2
+      mats[nn + tid] = pre.d; // dyn_r2
     if (!last) {
       for (int k = tid; k < nn; k += TPB) // ddyn_dx, ddyn_du, :365-366
         Am[k] = eb[o_a + k];
@@ -253,17 +347,18 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
   }
   if (WITH_RHS) { // q_mod, c_mod, r_mod (helpers.cpp:752-812)
     const double *wr_n = wr, *wr_e = wr + c + g;
-    for (int col = 0; col < ncols; ++col) {
-      const double *bc = b + col * b_col_stride, *bc_y = bc + ck.x_dim, *bc_z = bc_y + ck.y_dim;
-      double *vc = vecs + col * vecs_col_stride;
+    const int i = it.i;
+    for (int col = 0; col < ncols_rhs; ++col) {
+      const double *bc = it.b + col * b_col_stride, *bc_y = bc + ck.x_dim, *bc_z = bc_y + ck.y_dim;
+      double *vc = it.vecs + col * vecs_col_stride;
       if (col > 0) { // weighted right-hand side rows of this column
         __syncthreads();
-        for (int k = tid; k < nrows; k += TPB)
-          wr[k] = wl[k] * rhs_row(k, bc_y, bc_z);
+        for (int k = tid; k < it.nrows; k += TPB)
+          wr[k] = wl[k] * condense_rhs_row(it, k, bc_y, bc_z);
         __syncthreads();
       }
       if (tid < n) {
-        double acc = -bc[i * (n + m) + tid];
+        double acc = -(col == 0 ? pre.q : bc[i * (n + m) + tid]);
         acc = dot_seq<true>(acc, Jc + c * tid, wr_n, c);
         acc = dot_seq<true>(acc, Jg + g * tid, wr_n + c, g);
         if (!last) {
@@ -271,15 +366,120 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
           acc = dot_seq<true>(acc, Jxg + ge * tid, wr_e + ce, ge);
         }
         vc[tid] = acc;
-        vc[n + tid] = -bc_y[y_dyn + tid];
+        vc[n + tid] = -(col == 0 ? pre.dy : bc_y[it.y_dyn + tid]);
       } else if (!last && tid >= 32 && tid - 32 < m) { // another half of the wave: r_mod
         const int d = tid - 32;
-        double acc = -bc[i * (n + m) + n + d];
+        double acc = -(col == 0 ? pre.q : bc[i * (n + m) + n + d]);
         acc = dot_seq<true>(acc, Juc + ce * d, wr_e, ce);
         acc = dot_seq<true>(acc, Jug + ge * d, wr_e + ce, ge);
         vc[2 * n + d] = acc;
       }
     }
+  }
+}
+
+// WITH_RHS: also q_mod / r_mod / c_mod from b.  MATS = false (the split solve path): ONLY those --
+// the Jacobians of the stage are staged, no Q_mod / M_mod / R_mod / A / B work, `status` problems
+// with a failed factorization are skipped.
+template <bool WITH_RHS, bool MATS = true>
+__global__ void __launch_bounds__(TPB)
+condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, const double *__restrict__ r1_all,
+                      const double *__restrict__ inv_all, double *__restrict__ mats_all,
+                      const double *__restrict__ b_all, double *__restrict__ vecs_all, long batch,
+                      const int32_t *__restrict__ status = nullptr, const int ncols = 1,
+                      const long b_col_stride = 0, const long vecs_col_stride = 0) {
+  // ncols > 1 (the columns of J_theta, helpers.cpp:414-747): column j's right-hand side is
+  // b_all + j * b_col_stride, its q_mod / r_mod / c_mod go to vecs_all + j * vecs_col_stride; the
+  // Jacobians of the stage are staged once for all columns.
+  static_assert(MATS || WITH_RHS, "nothing to do");
+  extern __shared__ double sm[];
+  double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows, *r1s = wr + ck.lds_rows;
+  const long p = blockIdx.x / (ck.T + 1);
+  const int i = blockIdx.x - (unsigned)(p * (ck.T + 1));
+  if (p >= batch || (!MATS && status != nullptr && status[p] != 0))
+    return;
+  const int tid = threadIdx.x;
+  const CondenseItem it = condense_item<WITH_RHS>(ck, p, i, model_all, r1_all, inv_all, mats_all, b_all, vecs_all);
+  // Every small read of the wavefront is issued AHEAD of the stage copy: one HBM round trip per
+  // wavefront, not three.
+  CondensePre pre;
+  condense_prefetch<WITH_RHS, MATS>(ck, it, tid, pre);
+  // whole stage (node item + edge item are adjacent in the model arena) -> LDS
+  if (MATS) {
+    stage_copy2(buf, it.item, it.node_len + it.edge_len, tid);
+  } else { // the Jacobian tails only, at their usual places in the image
+    const int n = ck.n, m = ck.m, nn = n * n;
+    const int o_tail = it.node_len + 2 * nn + 2 * n * m + m * m;
+    if (it.last)
+      stage_copy2(buf + nn, it.item + nn, (it.c + it.g) * n, tid);
+    else
+      stage_copy_pair(buf + nn, it.item + nn, (it.c + it.g) * n, buf + o_tail, it.item + o_tail,
+                      (it.ce + it.ge) * (n + m), tid);
+  }
+  condense_commit<WITH_RHS, MATS>(ck, it, tid, pre, wl, wr, r1s);
+  __syncthreads();
+  condense_compute<WITH_RHS, MATS>(ck, it, tid, pre, buf, wl, wr, r1s, ncols, b_col_stride, vecs_col_stride);
+}
+
+// The same condensation, software-pipelined: a wavefront walks `per_block` consecutive stages and
+// has the NEXT stage's loads (its model image, 16 bytes per lane and piece, and the small reads) in
+// flight in registers while it computes the current one from LDS -- with one stage per wavefront
+// the load, compute and store phases of a wavefront do not overlap and the kernel ran at
+// load time + compute time + store time (245 + 180 + 110 us at the f1 shape).  Requires the stage
+// image to be one pass of 16-byte pieces: (node_len + edge_len) / 2 <= PIPE_U * 64, even lengths,
+// 16-byte aligned arenas (checked on the host).
+constexpr int PIPE_U = 8;
+template <bool WITH_RHS>
+__global__ void __launch_bounds__(TPB)
+condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_all,
+                           const double *__restrict__ r1_all, const double *__restrict__ inv_all,
+                           double *__restrict__ mats_all, const double *__restrict__ b_all,
+                           double *__restrict__ vecs_all, const long batch, const int per_block) {
+  extern __shared__ double sm[];
+  double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows, *r1s = wr + ck.lds_rows;
+  const int tid = threadIdx.x;
+  const long total = batch * (ck.T + 1);
+  const long first = (long)blockIdx.x * per_block;
+  const long end = first + per_block < total ? first + per_block : total;
+  if (first >= end)
+    return;
+  auto item_at = [&](const long idx) {
+    const long p = idx / (ck.T + 1);
+    return condense_item<WITH_RHS>(ck, p, (int)(idx - p * (ck.T + 1)), model_all, r1_all, inv_all, mats_all, b_all,
+                                   vecs_all);
+  };
+  auto image_load = [&](const CondenseItem &it, d2_t (&v)[PIPE_U]) {
+    const d2_t *s2 = (const d2_t *)it.item;
+    const int len2 = (it.node_len + it.edge_len) >> 1;
+#pragma unroll
+    for (int u = 0; u < PIPE_U; ++u)
+      v[u] = s2[min(tid + u * TPB, len2 - 1)];
+  };
+  CondenseItem cur = item_at(first);
+  CondensePre pre;
+  d2_t img[PIPE_U];
+  condense_prefetch<WITH_RHS, true>(ck, cur, tid, pre);
+  image_load(cur, img);
+  for (long idx = first; idx < end; ++idx) {
+    { // registers -> LDS
+      d2_t *d2 = (d2_t *)buf;
+      const int len2 = (cur.node_len + cur.edge_len) >> 1;
+#pragma unroll
+      for (int u = 0; u < PIPE_U; ++u)
+        if (tid + u * TPB < len2)
+          d2[tid + u * TPB] = img[u];
+    }
+    condense_commit<WITH_RHS, true>(ck, cur, tid, pre, wl, wr, r1s);
+    __syncthreads();
+    const CondensePre now = pre;
+    const CondenseItem nowit = cur;
+    if (idx + 1 < end) { // the next stage's loads fly during this stage's compute
+      cur = item_at(idx + 1);
+      condense_prefetch<WITH_RHS, true>(ck, cur, tid, pre);
+      image_load(cur, img);
+    }
+    condense_compute<WITH_RHS, true>(ck, nowit, tid, now, buf, wl, wr, r1s, 1, 0, 0);
+    __syncthreads(); // every reader of the LDS image is done before it is overwritten
   }
 }
 
@@ -307,9 +507,32 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
   const int y_dyn = i * (n + ck.cn), y_nc = y_dyn + n, y_ec = T * (n + ck.cn) + n + ck.cT + i * ck.ce;
   const int z_n = i * ck.gn, z_e = T * ck.gn + ck.gT + i * ck.ge;
   double *jn = sm, *je = jn + (c + g) * n, *xs = sm + ck.lds_tail, *us = xs + n;
-  stage_copy2(jn, item + nn, (c + g) * n, tid); // [dc_dx | dg_dx] of the node
-  if (!last)
-    stage_copy2(je, item + nn + (c + g) * n + 2 * nn + 2 * nm + m * m, (ce + ge) * (n + m), tid);
+  // column 0's small reads (stagewise solution, right-hand side and weight of the lane's constraint
+  // row) are issued ahead of the stage copy: one HBM round trip per wavefront instead of three
+  double pre_x = 0.0, pre_y = 0.0, pre_bn = 0.0, pre_wn = 0.0, pre_be = 0.0, pre_we = 0.0;
+  {
+    const double *b_y = b_all + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
+    const double *ls = lqr_sol_all + p * ck.vecs_len + (long)i * ck.vecs_stage;
+    if (tid < n) {
+      pre_x = ls[tid];
+      pre_y = ls[n + tid];
+    } else if (!last && tid >= 32 && tid - 32 < m) {
+      pre_x = ls[2 * n + (tid - 32)];
+    }
+    if (tid < c)
+      pre_bn = b_y[y_nc + tid], pre_wn = yinv[y_nc + tid];
+    else if (tid < c + g)
+      pre_bn = b_z[z_n + (tid - c)], pre_wn = zinv[z_n + (tid - c)];
+    if (tid < ce)
+      pre_be = b_y[y_ec + tid], pre_we = yinv[y_ec + tid];
+    else if (tid < ce + ge)
+      pre_be = b_z[z_e + (tid - ce)], pre_we = zinv[z_e + (tid - ce)];
+  }
+  if (last) // [dc_dx | dg_dx] of the node, [dc_dx | dc_du | dg_dx | dg_du] of the edge
+    stage_copy2(jn, item + nn, (c + g) * n, tid);
+  else
+    stage_copy_pair(jn, item + nn, (c + g) * n, je, item + nn + (c + g) * n + 2 * nn + 2 * nm + m * m,
+                    (ce + ge) * (n + m), tid);
   const double *Jxc = je, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
   for (int col = 0; col < ncols; ++col) { // ncols > 1: the columns of K^-1 J_theta, Jacobians staged once
     const double *b_y = b_all + col * b_col_stride + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
@@ -318,30 +541,33 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
     if (col > 0)
       __syncthreads(); // the previous column's readers of xs / us are done
     if (tid < n) {
-      const double xv = ls[tid];
+      const double xv = col == 0 ? pre_x : ls[tid];
       xs[tid] = xv;
       sol[i * (n + m) + tid] = xv;
-      sol_y[y_dyn + tid] = ls[n + tid];
+      sol_y[y_dyn + tid] = col == 0 ? pre_y : ls[n + tid];
     } else if (!last && tid >= 32 && tid - 32 < m) {
-      const double uv = ls[2 * n + (tid - 32)];
+      const double uv = col == 0 ? pre_x : ls[2 * n + (tid - 32)];
       us[tid - 32] = uv;
       sol[i * (n + m) + n + (tid - 32)] = uv;
     }
     __syncthreads();
     for (int k = tid; k < c + g; k += TPB) {
+      const bool pre = col == 0 && k == tid;
       if (k < c)
-        sol_y[y_nc + k] = (row_dot(jn, k, c, n, xs) - b_y[y_nc + k]) * yinv[y_nc + k];
+        sol_y[y_nc + k] = (row_dot(jn, k, c, n, xs) - (pre ? pre_bn : b_y[y_nc + k])) * (pre ? pre_wn : yinv[y_nc + k]);
       else
-        sol_z[z_n + (k - c)] = (row_dot(jn + c * n, k - c, g, n, xs) - b_z[z_n + (k - c)]) * zinv[z_n + (k - c)];
+        sol_z[z_n + (k - c)] = (row_dot(jn + c * n, k - c, g, n, xs) - (pre ? pre_bn : b_z[z_n + (k - c)])) *
+                               (pre ? pre_wn : zinv[z_n + (k - c)]);
     }
     for (int k = tid; k < ce + ge; k += TPB) {
+      const bool pre = col == 0 && k == tid;
       if (k < ce) {
         const double jx = row_dot(Jxc, k, ce, n, xs), ju = row_dot(Juc, k, ce, m, us);
-        sol_y[y_ec + k] = ((jx + ju) - b_y[y_ec + k]) * yinv[y_ec + k];
+        sol_y[y_ec + k] = ((jx + ju) - (pre ? pre_be : b_y[y_ec + k])) * (pre ? pre_we : yinv[y_ec + k]);
       } else {
         const int kk = k - ce;
         const double jx = row_dot(Jxg, kk, ge, n, xs), ju = row_dot(Jug, kk, ge, m, us);
-        sol_z[z_e + kk] = ((jx + ju) - b_z[z_e + kk]) * zinv[z_e + kk];
+        sol_z[z_e + kk] = ((jx + ju) - (pre ? pre_be : b_z[z_e + kk])) * (pre ? pre_we : zinv[z_e + kk]);
       }
     }
   }
@@ -384,24 +610,102 @@ apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ m
   // vector slices in LDS: x_i | u_i | ydyn_i | ydyn_{i+1} | yc_node | z_node | yc_edge | z_edge
   double *vx = v, *vu = vx + n, *vd = vu + m, *vdn = vd + n, *vyc = vdn + n, *vzn = vyc + c, *vye = vzn + g,
          *vze = vye + ce;
-  stage_copy2(buf, item, node_len + edge_len, tid);
-  for (int k = tid; k < n; k += TPB) {
-    vx[k] = x_x[x_s + k];
-    vd[k] = x_y[y_dyn + k];
-    if (!last)
-      vdn[k] = x_y[y_next + k];
+  // Output row r of the stage: where it lives in y, its regularization coefficient
+  // (r1 | r2 | w + r3) and, for a dynamics row of node i + 1, the -x_{i+1} entry.
+  const int n_rows = n + (last ? 0 : m + n) + c + g + ce + ge + (i == 0 ? n : 0);
+  auto row_io = [&](int q, double *&dst, double &coef, double &extra) {
+    extra = 0.0;
+    if (q < n) {
+      dst = y_x + x_s + q, coef = r1[x_s + q];
+      return;
+    }
+    q -= n;
+    if (!last) {
+      if (q < m) {
+        dst = y_x + x_u + q, coef = r1[x_u + q];
+        return;
+      }
+      q -= m;
+      if (q < n) {
+        dst = y_y + y_next + q, coef = r2[y_next + q], extra = x_x[x_s + n + m + q];
+        return;
+      }
+      q -= n;
+    }
+    if (q < c) {
+      dst = y_y + y_nc + q, coef = r2[y_nc + q];
+      return;
+    }
+    q -= c;
+    if (q < g) {
+      dst = y_z + z_n + q, coef = w[z_n + q] + r3[z_n + q];
+      return;
+    }
+    q -= g;
+    if (q < ce) {
+      dst = y_y + y_ec + q, coef = r2[y_ec + q];
+      return;
+    }
+    q -= ce;
+    if (q < ge) {
+      dst = y_z + z_e + q, coef = w[z_e + q] + r3[z_e + q];
+      return;
+    }
+    q -= ge;
+    dst = y_y + y_dyn + q, coef = r2[y_dyn + q];
+  };
+  // Every small read of the wavefront -- the slices of x and the lane's first output row -- is
+  // issued ahead of the stage copy: one HBM round trip per wavefront instead of three.
+  double *dst0 = nullptr;
+  double coef0 = 0.0, extra0 = 0.0, yold0 = 0.0;
+  if (tid < n_rows) {
+    row_io(tid, dst0, coef0, extra0);
+    yold0 = *dst0;
   }
-  if (!last)
-    for (int k = tid; k < m; k += TPB)
-      vu[k] = x_x[x_u + k];
-  for (int k = tid; k < c; k += TPB)
-    vyc[k] = x_y[y_nc + k];
-  for (int k = tid; k < g; k += TPB)
-    vzn[k] = x_z[z_n + k];
-  for (int k = tid; k < ce; k += TPB)
-    vye[k] = x_y[y_ec + k];
-  for (int k = tid; k < ge; k += TPB)
-    vze[k] = x_z[z_e + k];
+  double px = 0.0, pd = 0.0, pdn = 0.0, pu = 0.0, pyc = 0.0, pzn = 0.0, pye = 0.0, pze = 0.0;
+  if (tid < n) {
+    px = x_x[x_s + tid];
+    pd = x_y[y_dyn + tid];
+    if (!last)
+      pdn = x_y[y_next + tid];
+  }
+  if (!last && tid < m)
+    pu = x_x[x_u + tid];
+  if (tid < c)
+    pyc = x_y[y_nc + tid];
+  if (tid < g)
+    pzn = x_z[z_n + tid];
+  if (tid < ce)
+    pye = x_y[y_ec + tid];
+  if (tid < ge)
+    pze = x_z[z_e + tid];
+  stage_copy2(buf, item, node_len + edge_len, tid);
+  if (tid < n) {
+    vx[tid] = px;
+    vd[tid] = pd;
+    if (!last)
+      vdn[tid] = pdn;
+  }
+  if (!last && tid < m)
+    vu[tid] = pu;
+  if (tid < c)
+    vyc[tid] = pyc;
+  if (tid < g)
+    vzn[tid] = pzn;
+  if (tid < ce)
+    vye[tid] = pye;
+  if (tid < ge)
+    vze[tid] = pze;
+  for (int k = tid + TPB; k < c + g + ce + ge; k += TPB) { // more than 64 rows of one kind
+    if (k < c)
+      vyc[k] = x_y[y_nc + k];
+    if (k < g)
+      vzn[k] = x_z[z_n + k];
+    if (k < ce)
+      vye[k] = x_y[y_ec + k];
+    if (k < ge)
+      vze[k] = x_z[z_e + k];
+  }
   __syncthreads();
   const double *Q = buf, *Jc = buf + nn, *Jg = Jc + c * n, *eb = buf + node_len;
   const double *eQ = eb, *M = eb + nn, *R = M + nm, *A = R + m * m, *B = A + nn, *Jxc = B + nm, *Juc = Jxc + ce * n,
@@ -419,15 +723,20 @@ apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ m
       acc += a[r] * vec[r];
     return acc;
   };
-  const int n_rows = n + (last ? 0 : m + n) + c + g + ce + ge + (i == 0 ? n : 0);
   for (int r = tid; r < n_rows; r += TPB) {
     int q = r;
+    double *dst = dst0;
+    double coef = coef0, extra = extra0, yold = yold0;
+    if (r != tid) {
+      row_io(r, dst, coef, extra);
+      yold = *dst;
+    }
     if (q < n) { // state rows: H x + C^T y + G^T z + r1 x
       double acc = dotr(Q, n, q, n, vx) + dotc(Jc, c, q, c, vyc) + dotc(Jg, g, q, g, vzn) - vd[q];
       if (!last)
         acc += dotr(eQ, n, q, n, vx) + dotr(M, n, q, m, vu) + dotc(A, n, q, n, vdn) + dotc(Jxc, ce, q, ce, vye) +
                dotc(Jxg, ge, q, ge, vze);
-      y_x[x_s + q] += acc + r1[x_s + q] * vx[q];
+      *dst = yold + (acc + coef * vx[q]);
       continue;
     }
     q -= n;
@@ -435,38 +744,38 @@ apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ m
       if (q < m) { // control rows
         const double acc = dotc(M, n, q, n, vx) + dotr(R, m, q, m, vu) + dotc(B, n, q, n, vdn) +
                            dotc(Juc, ce, q, ce, vye) + dotc(Jug, ge, q, ge, vze);
-        y_x[x_u + q] += acc + r1[x_u + q] * vu[q];
+        *dst = yold + (acc + coef * vu[q]);
         continue;
       }
       q -= m;
       if (q < n) { // dynamics rows of node i + 1: A x + B u - x_{i+1} - r2 y
-        const double acc = dotr(A, n, q, n, vx) + dotr(B, n, q, m, vu) - x_x[x_s + n + m + q];
-        y_y[y_next + q] += acc - r2[y_next + q] * vdn[q];
+        const double acc = dotr(A, n, q, n, vx) + dotr(B, n, q, m, vu) - extra;
+        *dst = yold + (acc - coef * vdn[q]);
         continue;
       }
       q -= n;
     }
     if (q < c) {
-      y_y[y_nc + q] += dotr(Jc, c, q, n, vx) - r2[y_nc + q] * vyc[q];
+      *dst = yold + (dotr(Jc, c, q, n, vx) - coef * vyc[q]);
       continue;
     }
     q -= c;
     if (q < g) {
-      y_z[z_n + q] += dotr(Jg, g, q, n, vx) - (w[z_n + q] + r3[z_n + q]) * vzn[q];
+      *dst = yold + (dotr(Jg, g, q, n, vx) - coef * vzn[q]);
       continue;
     }
     q -= g;
     if (q < ce) {
-      y_y[y_ec + q] += dotr(Jxc, ce, q, n, vx) + dotr(Juc, ce, q, m, vu) - r2[y_ec + q] * vye[q];
+      *dst = yold + (dotr(Jxc, ce, q, n, vx) + dotr(Juc, ce, q, m, vu) - coef * vye[q]);
       continue;
     }
     q -= ce;
     if (q < ge) {
-      y_z[z_e + q] += dotr(Jxg, ge, q, n, vx) + dotr(Jug, ge, q, m, vu) - (w[z_e + q] + r3[z_e + q]) * vze[q];
+      *dst = yold + (dotr(Jxg, ge, q, n, vx) + dotr(Jug, ge, q, m, vu) - coef * vze[q]);
       continue;
     }
     q -= ge; // i == 0: the root's dynamics rows, -x_root - r2 y (helpers.cpp:1081-1085)
-    y_y[y_dyn + q] += -vx[q] - r2[y_dyn + q] * vd[q];
+    *dst = yold + (-vx[q] - coef * vd[q]);
   }
 }
 

@@ -36,6 +36,7 @@ struct sip_kkt_plan {
   void *d_ints = nullptr, *d_longs = nullptr;
   sipamd::kkt::Meta meta{};
   bool chain_kernels = false; // uniform chain: arithmetic-offset kernels (kkt_chain_kernels.hpp)
+  int chain_pipe = 0;         // > 0: stages per wavefront of the software-pipelined condensation
   sipamd::kkt::ChainKkt ck{};
   size_t lds_chain_condense = 0, lds_chain_recover = 0, lds_chain_apply = 0;
   // theta (sip_kkt_plan_set_theta)
@@ -150,7 +151,19 @@ hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double
   if (per > 0)
     hipLaunchKernelGGL(sipamd::kkt::weights_kernel, dim3((unsigned)((p->batch * per + 255) / 256)), dim3(256), 0, s,
                        p->meta, w, r2, r3, r.inv, r.reg, (long)p->batch);
-  if (p->chain_kernels && b != nullptr)
+  // the pipelined kernel copies 16-byte pieces: the arena itself has to be 16-byte aligned
+  const bool pipe = p->chain_kernels && p->chain_pipe > 0 && ((uintptr_t)model & 15) == 0;
+  const unsigned pipe_grid =
+      pipe ? (unsigned)(((long)p->batch * p->N + p->chain_pipe - 1) / p->chain_pipe) : 0u;
+  if (pipe && b != nullptr)
+    hipLaunchKernelGGL(sipamd::kkt::condense_chain_pipe_kernel<true>, dim3(pipe_grid), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch,
+                       p->chain_pipe);
+  else if (pipe)
+    hipLaunchKernelGGL(sipamd::kkt::condense_chain_pipe_kernel<false>, dim3(pipe_grid), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, (const double *)nullptr,
+                       (double *)nullptr, (long)p->batch, p->chain_pipe);
+  else if (p->chain_kernels && b != nullptr)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
                        p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
   else if (p->chain_kernels)
@@ -397,11 +410,25 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
     ck.lds_item = even(n * n + cgn * n + ck.edge_len);
     ck.lds_tail = even(cgn * n + cge * (n + mm)); // recover: every Jacobian of a stage
     ck.lds_rows = even(cgn + cge);                // condense: weights | weighted rhs rows
-    p->lds_chain_condense = sizeof(double) * ((size_t)ck.lds_item + 2 * (size_t)ck.lds_rows);
+    p->lds_chain_condense = sizeof(double) * ((size_t)ck.lds_item + 2 * (size_t)ck.lds_rows + n + mm);
     p->lds_chain_recover = sizeof(double) * ((size_t)ck.lds_tail + n + mm);
     p->lds_chain_apply = sizeof(double) * ((size_t)ck.lds_item + 3 * n + mm + (size_t)ck.lds_rows);
-    p->chain_kernels = p->lds_chain_condense <= 48 * 1024 &&
+    // lane maps of the chain kernels: state rows on lanes 0..n-1, control rows on lanes 32..32+m-1
+    p->chain_kernels = p->lds_chain_condense <= 48 * 1024 && n <= 32 && mm <= 32 &&
                        !(variant && std::strcmp(variant, "tables") == 0);
+  }
+  if (p->chain_kernels) {
+    // software-pipelined condensation (SIP_KKT_PIPE = stages per wavefront, 0 = off): the stage
+    // image must be one pass of 16-byte pieces at every stage
+    const sipamd::kkt::ChainKkt &ck = p->ck;
+    const int n = ck.n;
+    const int len_mid = ck.node_len + ck.edge_len, len_last = n * n + (ck.cT + ck.gT) * n;
+    const char *pe = std::getenv("SIP_KKT_PIPE");
+    const int per = pe ? std::atoi(pe) : 6;
+    const bool fits = len_mid % 2 == 0 && len_last % 2 == 0 && ck.model_len % 2 == 0 &&
+                      len_mid / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB &&
+                      len_last / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB;
+    p->chain_pipe = fits && per > 0 ? per : 0;
   }
   p->name += p->chain_kernels ? " + chain condensation" : p->staged ? " + staged condensation" : " + direct condensation";
 

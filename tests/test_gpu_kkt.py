@@ -240,6 +240,27 @@ def test_condensation_variants_agree_bitwise(monkeypatch):
     assert torch.equal(sol_d, sol_s)
 
 
+def test_pipelined_condensation_is_bitwise_the_one_stage_kernel(monkeypatch):
+    """SIP_KKT_PIPE = stages per wavefront of the software-pipelined condensation (0 = one stage per
+    wavefront): same arithmetic, so the solutions are bit-identical -- also when batch x stages is
+    not a multiple of the stages per wavefront, and with a stage image of an odd number of 16-byte
+    pieces per lane."""
+    for (n, m, T, batch) in ((6, 2, 9, 5), (12, 4, 10, 7), (4, 4, 3, 3)):
+        dims = rk.newton_kkt_dims(n, m, T)
+        arrays = rk.newton_kkt_problem(dims, seed=5, batch=batch, r2_max=1e2)
+        d = _dev(*arrays)
+        sols = {}
+        for pipe in ("0", "1", "4", "6", "1000"):
+            monkeypatch.setenv("SIP_KKT_PIPE", pipe)
+            kkt = _make(dims, batch)
+            sol, st = kkt.factor_solve(*d)
+            assert st.cpu().tolist() == [0] * batch
+            kkt.factor(*d[:5])
+            sols[pipe] = (sol.clone(), kkt.solve(d[0], d[5]).clone())
+        for pipe in ("1", "4", "6", "1000"):
+            assert torch.equal(sols[pipe][0], sols["0"][0]) and torch.equal(sols[pipe][1], sols["0"][1]), (n, m, pipe)
+
+
 def test_theta_schur_reference_case():
     """CallbackProvider.SolvesBranchedSystemWithSchurVariables (variable_dimensions_test.cpp:338-363):
     theta_dim = 2 on the branched tree; K * solution == rhs to 1e-8, and agreement with the oracle."""
