@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "generic_plan.hpp"
+#include "stream_fill.hpp"
 #include "kkt_chain_kernels.hpp"
 #include "kkt_kernels.hpp"
 #include "kkt_theta_kernels.hpp"
@@ -144,7 +145,7 @@ int even(int v) { return (v + 1) / 2 * 2; }
 hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double *model, const double *w,
                            const double *r1, const double *r2, const double *r3, const double *b,
                            hipStream_t s) {
-  hipError_t e = hipMemsetAsync(r.reg, 0, (size_t)p->batch * sizeof(int), s);
+  hipError_t e = sipamd::zero_async(r.reg, (size_t)p->batch * sizeof(int), s); // a kernel: stream_fill.hpp
   if (e != hipSuccess)
     return e;
   const long per = (long)p->y_dim + p->z_dim;

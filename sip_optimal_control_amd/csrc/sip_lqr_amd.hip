@@ -17,6 +17,7 @@
 #include "chain_mf32.hpp"
 #include "chain_qw16.hpp"
 #include "generic_plan.hpp"
+#include "stream_fill.hpp"
 
 struct sip_lqr_plan {
   int dtype;
@@ -346,7 +347,7 @@ hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, 
   if (!p->padded) {
     const void *v = vecs;
     if (v == nullptr) {
-      e = hipMemsetAsync(w + f.vecs, 0, f.sol - f.vecs, s);
+      e = sipamd::zero_async(w + f.vecs, f.sol - f.vecs, s);
       v = w + f.vecs;
     }
     if (e == hipSuccess)
@@ -363,7 +364,7 @@ hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, 
     hipLaunchKernelGGL(pad_vecs_kernel<true>, grid(B * d.pvecs_len), dim3(256), 0, s, d, (const double *)vecs,
                        (double *)(w + f.vecs), B);
   else
-    e = hipMemsetAsync(w + f.vecs, 0, f.sol - f.vecs, s);
+    e = sipamd::zero_async(w + f.vecs, f.sol - f.vecs, s);
   if (e == hipSuccess)
     e = p->launch_fs(p, w + f.pmats, w + f.vecs, w + f.sol, w + f.pgains, status, ws, s, mode, w + f.gfac);
   if (e == hipSuccess && sol != nullptr)
@@ -613,7 +614,7 @@ int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
     char *w = (char *)d_workspace;
     hipError_t e = run_fused(plan, d_mats, nullptr, nullptr, d_gains, d_status, d_workspace, s, 1);
     if (e == hipSuccess)
-      e = hipMemcpyAsync(w + f.status, d_status, (size_t)plan->batch * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+      e = sipamd::copy_async(w + f.status, d_status, (size_t)plan->batch * sizeof(int32_t), s);
     return report(e, "sip_lqr_factor(fused)");
   }
   hipError_t e = ensure_generic(plan);
@@ -622,8 +623,7 @@ int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
             ? plan->gen.launch_factor<float>(plan->batch, d_mats, d_workspace, d_gains, d_status, s)
             : plan->gen.launch_factor<double>(plan->batch, d_mats, d_workspace, d_gains, d_status, s);
   if (e == hipSuccess) // keep the statuses for sip_lqr_solve
-    e = hipMemcpyAsync(generic_status(plan, d_workspace), d_status, (size_t)plan->batch * sizeof(int32_t),
-                       hipMemcpyDeviceToDevice, s);
+    e = sipamd::copy_async(generic_status(plan, d_workspace), d_status, (size_t)plan->batch * sizeof(int32_t), s);
   return report(e, "sip_lqr_factor");
 }
 

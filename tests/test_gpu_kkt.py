@@ -356,8 +356,10 @@ def test_full_size_properties():
 def test_step_is_hip_graph_capturable():
     """The fused Newton-KKT step and the Riccati sweep only enqueue work on the caller's stream (no
     host synchronisation, no host-side allocation), so a Newton loop can be captured once in a
-    hipGraph and replayed: new right-hand sides are picked up from the captured buffers.  Capture
-    and replay on an explicit (non-default) stream."""
+    hipGraph and replayed: new right-hand sides are picked up from the captured buffers.  Captured on
+    a side stream (torch's rule), replayed both there and on the default stream -- the usual
+    torch.cuda.graph flow.  (A hipMemsetAsync inside the step used to become a memset node that a
+    default-stream replay skipped: csrc/stream_fill.hpp.)"""
     from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
     dims = rk.newton_kkt_dims(12, 4, 20)
     batch = 16
@@ -381,13 +383,15 @@ def test_step_is_hip_graph_capturable():
     with torch.cuda.graph(graph, stream=side):
         kkt.factor_solve(*d, sol=sol)
         lqr.factor_solve(mats, vecs, lsol, lgains)
-    with torch.cuda.stream(side):
-        for _ in range(2):  # a new right-hand side in the captured buffer, then replay
+    for stream in (side, torch.cuda.current_stream(), side, torch.cuda.current_stream()):
+        with torch.cuda.stream(stream):  # a new right-hand side in the captured buffer, then replay
             d[5].copy_(torch.roll(d[5], 1, dims=0))
             lsol.zero_()
+            sol.zero_()
             graph.replay()
-            side.synchronize()
-            ref, st = oracle_kkt.batch(*[a.cpu().numpy() for a in d])
-            assert st.tolist() == [0] * batch
-            assert (np.abs(sol.cpu().numpy() - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= REL
-            assert torch.equal(lsol, eager_lqr)
+        torch.cuda.synchronize()
+        assert kkt.status.cpu().tolist() == [0] * batch
+        ref, st = oracle_kkt.batch(*[a.cpu().numpy() for a in d])
+        assert st.tolist() == [0] * batch
+        assert (np.abs(sol.cpu().numpy() - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= REL
+        assert torch.equal(lsol, eager_lqr)
