@@ -228,7 +228,8 @@ typedef const __attribute__((address_space(3))) double lds_cdouble;
 // per problem) for the 4 problems of a wave: `global_load_lds_dwordx4` writes
 // LDS as wave-uniform base + lane*16, so instruction j fills image bytes
 // [1024 j, 1024 j + 1024) and each lane picks the global piece that belongs
-// there.  Image: problem rr of the wave at byte rr * PIECES * 16.
+// there.  Image: problem rr of the wave at byte rr * PIECES * 16; the image is padded to whole
+// instructions (INSTR * 1024 bytes).
 template <int PIECES>
 struct StageDma {
   static constexpr int INSTR = (4 * PIECES + 63) / 64;
@@ -239,7 +240,8 @@ struct StageDma {
                                        const unsigned max_rel) {
     sfor<0, INSTR>([&](auto jj) {
       constexpr int j = decltype(jj)::value;
-      const unsigned q = j * 64 + lane;
+      // lanes past the last piece re-read it (their LDS slots are padding of the image)
+      const unsigned q = (unsigned)(j * 64 + lane) < 4u * PIECES ? (unsigned)(j * 64 + lane) : 4u * PIECES - 1u;
       unsigned rr = q / PIECES;
       const unsigned within = q - rr * PIECES;
       rr = rr < max_rel ? rr : max_rel;
@@ -251,20 +253,14 @@ struct StageDma {
   template <int AUX = 0>
   __device__ __forceinline__ void issue(const char *base, lds_char *dst,
                                         const int lane) const {
+    // Every instruction is issued by the whole wave, never under a lane predicate: two
+    // identically predicated tails in a row (e.g. 4 * 305 and 4 * 17 pieces: lanes < 4 both) were
+    // tail-merged by the compiler into ONE instruction whose LDS base -- a wave-uniform M0 value --
+    // became a per-lane PHI read with v_readfirstlane, which scattered one image into the other.
     sfor<0, INSTR>([&](auto jj) {
       constexpr int j = decltype(jj)::value;
-      if constexpr (j * 64 + 63 < 4 * PIECES) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(base + off[j]),
-            (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0,
-            AUX);
-      } else {
-        if (j * 64 + lane < 4 * PIECES)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void *)(base + off[j]),
-              (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
-              0, AUX);
-      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off[j]),
+                                       (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, AUX);
     });
   }
 };

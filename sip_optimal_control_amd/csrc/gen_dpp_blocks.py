@@ -126,7 +126,7 @@ def emit_x(out, kind, R, K):
     out.append("}\n")
 
 
-XSIZES = [1, 2, 3, 4, 6, 8, 12, 14, 15, 16]
+XSIZES = list(range(1, 17))
 
 
 def main(path):

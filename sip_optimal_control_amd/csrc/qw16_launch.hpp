@@ -1,0 +1,68 @@
+// qw16_launch.hpp -- host-side launcher and table entry of the fused chain kernels, shared by the
+// translation units that instantiate them (sip_lqr_amd.hip: the benchmark shapes and the hosts of
+// the embedding; qw16_extra.hip, compiled in slices: every other shape n <= 16, m <= 8).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/sip_lqr_amd.h"
+#include "chain_qw16.hpp"
+
+#ifdef SIP_LQR_STAMPS
+// Diagnostic build: device buffer of 8 x u64 per wave, set by the tool (sip_lqr_amd.hip).
+extern unsigned long long *g_sip_lqr_stamps;
+#define SIP_STAMP_PASS , g_sip_lqr_stamps
+#else
+#define SIP_STAMP_PASS
+#endif
+
+namespace sipamd {
+
+// mode: 0 fused factor + solve, 1 factor only (+ the G factors to gfac), 2 solve only
+typedef hipError_t (*launch_fs_t)(long batch, int T, const void *mats, const void *vecs, void *sol, void *gains,
+                                  int32_t *status, void *ws, hipStream_t stream, int mode, void *gfac);
+
+struct KernelEntry {
+  int dtype, n, m;
+  const char *name;
+  int ws_slot; // scalars of workspace per node
+  launch_fs_t launch_fs;
+};
+
+template <int N, int M, bool STAGED, bool WPACK>
+hipError_t launch_qw16(long batch, int T, const void *mats, const void *vecs, void *sol, void *gains,
+                       int32_t *status, void *ws, hipStream_t stream, int mode, void *gfac) {
+  using Cfg = StagedCfg<N, M, WPACK>;
+  const unsigned blocks = (unsigned)((batch + 3) / 4);
+  const unsigned lds = STAGED ? Cfg::LDS_BYTES : 0;
+  if (STAGED) {
+    // LDS-DMA moves 16-byte pieces: every base must be 16-byte aligned.
+    const uintptr_t bits = (uintptr_t)mats | (uintptr_t)vecs | (uintptr_t)gains | (uintptr_t)ws;
+    if (bits & 15)
+      return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL((chain_factor_solve_qw16<N, M, STAGED, WPACK>), dim3(blocks), dim3(64), lds, stream,
+                     (const double *)mats, (const double *)vecs, (double *)sol, (double *)gains, (double *)ws,
+                     (int *)status, batch, T, mode, (double *)gfac SIP_STAMP_PASS);
+  return hipGetLastError();
+}
+
+// The shapes n <= 16, m <= 8 that sip_lqr_amd.hip does not instantiate itself live in eight slices
+// of qw16_extra.hip (compiled in parallel): slice s defines qw16_extra_slice_<s>.
+constexpr int kQw16ExtraSlices = 8;
+#define SIP_QW16_DECLARE_SLICE(S) const KernelEntry *qw16_extra_slice_##S(int *count);
+SIP_QW16_DECLARE_SLICE(0) SIP_QW16_DECLARE_SLICE(1) SIP_QW16_DECLARE_SLICE(2) SIP_QW16_DECLARE_SLICE(3)
+SIP_QW16_DECLARE_SLICE(4) SIP_QW16_DECLARE_SLICE(5) SIP_QW16_DECLARE_SLICE(6) SIP_QW16_DECLARE_SLICE(7)
+#undef SIP_QW16_DECLARE_SLICE
+
+} // namespace sipamd
+
+// direct: every lane loads its columns from global memory (any N <= 16)
+#define QW16_DIRECT(N, M)                                                                                     \
+  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",direct>/f64",                                   \
+    sipamd::StagedCfg<N, M, false>::WSN, &sipamd::launch_qw16<N, M, false, false> }
+// staged: LDS-DMA double buffering + packed symmetric S spill (N, M even, N <= 14)
+#define QW16_STAGED(N, M)                                                                                     \
+  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",staged>/f64",                                   \
+    sipamd::StagedCfg<N, M, true>::WSN, &sipamd::launch_qw16<N, M, true, true> }

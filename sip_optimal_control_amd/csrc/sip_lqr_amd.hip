@@ -15,8 +15,8 @@
 #include <memory>
 
 #include "chain_mf32.hpp"
-#include "chain_qw16.hpp"
 #include "generic_plan.hpp"
+#include "qw16_launch.hpp"
 #include "stream_fill.hpp"
 
 struct sip_lqr_plan {
@@ -27,8 +27,7 @@ struct sip_lqr_plan {
   int ws_slot; // scalars of workspace per node of the fused kernel (0: none)
   // fused factor+solve launcher of a dedicated kernel; nullptr: the general
   // engine (tree_generic.hpp) runs factor then solve
-  hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
-                          void *, void *, int32_t *, void *, hipStream_t, int, void *);
+  sipamd::launch_fs_t launch_fs;
   // General engine on the packed chain layout: serves shapes / dtypes without
   // a dedicated kernel and the split factor / solve entry points.  Tables are
   // laid out at plan creation (host only), uploaded at first use.
@@ -50,65 +49,23 @@ struct sip_lqr_plan {
 
 #ifdef SIP_LQR_STAMPS
 // Diagnostic build: device buffer of 8 x u64 per wave, set by the tool.
-static unsigned long long *g_stamps = nullptr;
-extern "C" void sip_lqr_debug_set_stamps(void *p) {
-  g_stamps = (unsigned long long *)p;
-}
-#define SIP_STAMP_PASS , g_stamps
-#else
-#define SIP_STAMP_PASS
+unsigned long long *g_sip_lqr_stamps = nullptr;
+extern "C" void sip_lqr_debug_set_stamps(void *p) { g_sip_lqr_stamps = (unsigned long long *)p; }
 #endif
 
 namespace {
 
-template <int N, int M, bool STAGED, bool WPACK>
-hipError_t launch_qw16(const sip_lqr_plan *pl, const void *mats,
-                       const void *vecs, void *sol, void *gains,
-                       int32_t *status, void *ws, hipStream_t stream, int mode, void *gfac) {
-  using Cfg = sipamd::StagedCfg<N, M, WPACK>;
-  const long batch = pl->batch;
-  const unsigned blocks = (unsigned)((batch + 3) / 4);
-  const unsigned lds = STAGED ? Cfg::LDS_BYTES : 0;
-  if (STAGED) {
-    // LDS-DMA moves 16-byte pieces: every base must be 16-byte aligned.
-    const uintptr_t bits = (uintptr_t)mats | (uintptr_t)vecs | (uintptr_t)gains |
-                           (uintptr_t)ws;
-    if (bits & 15)
-      return hipErrorInvalidValue;
-  }
-  hipLaunchKernelGGL((sipamd::chain_factor_solve_qw16<N, M, STAGED, WPACK>),
-                     dim3(blocks), dim3(64), lds, stream, (const double *)mats,
-                     (const double *)vecs, (double *)sol, (double *)gains,
-                     (double *)ws, (int *)status, batch, pl->T, mode, (double *)gfac SIP_STAMP_PASS);
-  return hipGetLastError();
-}
-
 template <int M>
-hipError_t launch_mf32(const sip_lqr_plan *pl, const void *mats, const void *vecs, void *sol, void *gains,
+hipError_t launch_mf32(long batch, int T, const void *mats, const void *vecs, void *sol, void *gains,
                        int32_t *status, void *ws, hipStream_t stream, int /*mode: always the full sweep*/,
                        void * /*gfac*/) {
-  hipLaunchKernelGGL((sipamd::mf32::chain_factor_solve_mf32<M>), dim3((unsigned)pl->batch), dim3(64), 0,
+  hipLaunchKernelGGL((sipamd::mf32::chain_factor_solve_mf32<M>), dim3((unsigned)batch), dim3(64), 0,
                      stream, (const float *)mats, (const float *)vecs, (float *)sol, (float *)gains,
-                     (float *)ws, (int *)status, (long)pl->batch, pl->T SIP_STAMP_PASS);
+                     (float *)ws, (int *)status, batch, T SIP_STAMP_PASS);
   return hipGetLastError();
 }
 
-struct KernelEntry {
-  int dtype, n, m;
-  const char *name;
-  int ws_slot;
-  hipError_t (*launch_fs)(const sip_lqr_plan *, const void *, const void *,
-                          void *, void *, int32_t *, void *, hipStream_t, int, void *);
-};
-
-// direct: every lane loads its columns from global memory (any N <= 15)
-#define QW16_DIRECT(N, M)                                                      \
-  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",direct>/f64",    \
-    sipamd::StagedCfg<N, M, false>::WSN, &launch_qw16<N, M, false, false> }
-// staged: LDS-DMA double buffering + packed symmetric W spill (N, M even)
-#define QW16_STAGED(N, M)                                                      \
-  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",staged>/f64",    \
-    sipamd::StagedCfg<N, M, true>::WSN, &launch_qw16<N, M, true, true> }
+using sipamd::KernelEntry;
 
 // First match wins; SIP_LQR_VARIANT=direct|staged (tests, A/B timing) narrows
 // the search to kernels whose name carries that tag.
@@ -135,13 +92,37 @@ const KernelEntry kKernels[] = {
     QW16_DIRECT(16, 1), QW16_DIRECT(16, 2), QW16_DIRECT(16, 3), QW16_DIRECT(16, 4), QW16_DIRECT(16, 8),
 };
 
+// Every other shape n <= 16, m <= 8 (qw16_extra.hip, compiled in SIP_QW16_SLICES slices).
+// SIP_LQR_EXTRA=0 (tests of the embedding) hides them.
+template <typename F> void for_each_kernel(F &&f) {
+  for (const auto &k : kKernels)
+    f(k);
+#ifndef SIP_QW16_NO_EXTRA
+  const char *extra = std::getenv("SIP_LQR_EXTRA");
+  if (extra != nullptr && extra[0] == '0')
+    return;
+  typedef const KernelEntry *(*slice_fn)(int *);
+  static const slice_fn slices[sipamd::kQw16ExtraSlices] = {
+      sipamd::qw16_extra_slice_0, sipamd::qw16_extra_slice_1, sipamd::qw16_extra_slice_2, sipamd::qw16_extra_slice_3,
+      sipamd::qw16_extra_slice_4, sipamd::qw16_extra_slice_5, sipamd::qw16_extra_slice_6, sipamd::qw16_extra_slice_7};
+  for (const slice_fn fn : slices) {
+    int count = 0;
+    const KernelEntry *table = fn(&count);
+    for (int e = 0; e < count; ++e)
+      f(table[e]);
+  }
+#endif
+}
+
 const KernelEntry *find_kernel(int dtype, int n, int m) {
   const char *want = std::getenv("SIP_LQR_VARIANT");
-  for (const auto &k : kKernels)
-    if (k.dtype == dtype && k.n == n && k.m == m &&
+  const KernelEntry *found = nullptr;
+  for_each_kernel([&](const KernelEntry &k) {
+    if (found == nullptr && k.dtype == dtype && k.n == n && k.m == m &&
         (want == nullptr || want[0] == 0 || std::strstr(k.name, want)))
-      return &k;
-  return nullptr;
+      found = &k;
+  });
+  return found;
 }
 
 // Smallest fused fp64 kernel that can embed an (n, m) chain: least N, then a staged kernel with
@@ -351,7 +332,7 @@ hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, 
       v = w + f.vecs;
     }
     if (e == hipSuccess)
-      e = p->launch_fs(p, mats, v, sol ? sol : (void *)(w + f.sol), gains, status, ws, s, mode, w + f.gfac);
+      e = p->launch_fs(p->batch, p->T, mats, v, sol ? sol : (void *)(w + f.sol), gains, status, ws, s, mode, w + f.gfac);
     return e;
   }
   const PadDims d = pad_dims(p);
@@ -366,7 +347,7 @@ hipError_t run_fused(const sip_lqr_plan *p, const void *mats, const void *vecs, 
   else
     e = sipamd::zero_async(w + f.vecs, f.sol - f.vecs, s);
   if (e == hipSuccess)
-    e = p->launch_fs(p, w + f.pmats, w + f.vecs, w + f.sol, w + f.pgains, status, ws, s, mode, w + f.gfac);
+    e = p->launch_fs(p->batch, p->T, w + f.pmats, w + f.vecs, w + f.sol, w + f.pgains, status, ws, s, mode, w + f.gfac);
   if (e == hipSuccess && sol != nullptr)
     hipLaunchKernelGGL(pad_vecs_kernel<false>, grid(B * d.vecs_len), dim3(256), 0, s, d, (const double *)(w + f.sol),
                        (double *)sol, B);

@@ -56,7 +56,9 @@ def main():
             else:
                 off = sh.mats_off(stage)["Q"]
                 mats[bad, off:off + n * n] = -1e3 * torch.eye(n, dtype=torch.float64, device="cuda:0").reshape(-1)
+        os.environ["SIP_LQR_EXTRA"] = "0" if rng.random() < 0.25 else "1"  # a quarter through the embedding
         s = BatchedChainLQR(n, m, T, batch)
+        os.environ.pop("SIP_LQR_EXTRA")
         kernels[s.kernel_name.split("/")[0].split(" embedding")[0] + (" (embedded)" if "embedding" in s.kernel_name else "")] = 1
         sol, gains, st = s.factor_solve(mats, vecs)
         torch.cuda.synchronize()

@@ -91,6 +91,16 @@ def test_kernel_selection_and_embedding(lib, monkeypatch):
             kernel, _ = name(n, m)
             assert f"qw16<{n},{m}," in kernel and "embedding" not in kernel
             assert ("staged" in kernel) == (m % 2 == 0)
+    # every fp64 shape n <= 16, m <= 8 has an exact kernel (qw16_extra.hip); staged when both are even
+    for n in range(1, 17):
+        for m in range(1, 9):
+            kernel, _ = name(n, m)
+            assert f"qw16<{n},{m}," in kernel and "embedding" not in kernel, (n, m, kernel)
+            if n % 2 == 0 and m % 2 == 0 and n <= 14:
+                assert "staged" in kernel, (n, m, kernel)
+    assert "tree_generic" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
+    # without the extra slices (diagnostic builds; SIP_LQR_EXTRA=0): embedding in the next larger kernel
+    monkeypatch.setenv("SIP_LQR_EXTRA", "0")
     assert name(10, 3)[0] == "chain_factor_solve_qw16<12,4,staged>/f64 embedding (10,3)"
     assert name(5, 3)[0].startswith("chain_factor_solve_qw16<6,4,staged>")
     assert name(13, 5)[0].startswith("chain_factor_solve_qw16<14,8,staged>")

@@ -32,7 +32,7 @@ def _make(n, m, T, batch, seed, dtype=None):
 @pytest.mark.parametrize("n,m,T,batch", [(17, 4, 16, 5), (5, 3, 7, 9), (7, 1, 4, 3), (15, 16, 3, 2)])
 def test_general_engine_fp64_matches_oracle(oracle_lib, monkeypatch, n, m, T, batch):
     from sip_optimal_control_amd import BatchedChainLQR
-    monkeypatch.setenv("SIP_LQR_PAD", "0")  # no embedding in a larger fused kernel
+    monkeypatch.setenv("SIP_LQR_VARIANT", "general")  # also for the shapes with a fused kernel
     mats, vecs = _make(n, m, T, batch, seed=50 + n)
     solver = BatchedChainLQR(n, m, T, batch)
     assert "tree_generic" in solver.kernel_name
@@ -49,11 +49,13 @@ def test_general_engine_fp64_matches_oracle(oracle_lib, monkeypatch, n, m, T, ba
     (11, 4, 12, 5, "<12,4,staged>"), (9, 2, 9, 7, "<12,2,staged>"), (3, 1, 6, 4, "<3,2,direct>"),
     (5, 3, 0, 2, "<6,4,staged>"), (13, 4, 10, 6, "<14,4,staged>"), (13, 5, 8, 5, "<14,8,staged>"),
     (10, 6, 8, 5, "<12,8,staged>"), (15, 3, 5, 3, "<15,4,direct>"), (16, 6, 6, 5, "<16,8,direct>")])
-def test_embedding_in_the_next_fused_kernel(oracle_lib, n, m, T, batch, host):
-    """Uniform shapes without an exact kernel run on the next larger fused kernel: the extra states
-    and controls decouple exactly, so the real components match the oracle as usual.  Fused and
-    split entry points, one failing problem."""
+def test_embedding_in_the_next_fused_kernel(oracle_lib, monkeypatch, n, m, T, batch, host):
+    """Without the exact kernels of qw16_extra.hip (SIP_LQR_EXTRA=0; diagnostic builds leave them
+    out) a uniform shape runs on the next larger fused kernel: the extra states and controls
+    decouple exactly, so the real components match the oracle as usual.  Fused and split entry
+    points, one failing problem."""
     from sip_optimal_control_amd import BatchedChainLQR, ChainShape
+    monkeypatch.setenv("SIP_LQR_EXTRA", "0")
     mats, vecs = _make(n, m, T, batch, seed=500 + 10 * n + m)
     if T > 1 and batch > 2:
         off = ChainShape(n, m, T).mats_off(1)["R"]
@@ -74,6 +76,33 @@ def test_embedding_in_the_next_fused_kernel(oracle_lib, n, m, T, batch, host):
         np.testing.assert_array_equal(st2.cpu().numpy(), ref_status)
         assert _rel(s2.cpu().numpy()[ok], ref_sol[ok]) <= 1e-9
         assert _rel(g2.cpu().numpy()[ok], ref_gains[ok]) <= 1e-9
+
+
+@pytest.mark.parametrize("n", list(range(1, 17)))
+def test_every_shape_up_to_16x8_has_an_exact_kernel(oracle_lib, n):
+    """qw16_extra.hip: every fp64 chain shape n <= 16, m <= 8 runs on its own instantiation of the
+    fused kernel (staged when n and m are even, n <= 14).  Fused and split entry points against
+    the oracle, one problem with an indefinite R (G failure) in the batch."""
+    from sip_optimal_control_amd import BatchedChainLQR, ChainShape
+    for m in range(1, 9):
+        T, batch = 3 + (n + m) % 5, 9
+        mats, vecs = _make(n, m, T, batch, seed=7000 + 10 * n + m)
+        off = ChainShape(n, m, T).mats_off(1)["R"]
+        mats[2, off:off + m * m] = -1e3 * torch.eye(m, dtype=torch.float64, device="cuda:0").reshape(-1)
+        solver = BatchedChainLQR(n, m, T, batch)
+        assert f"qw16<{n},{m}," in solver.kernel_name and "embedding" not in solver.kernel_name
+        sol, gains, status = solver.factor_solve(mats, vecs)
+        g2, st2 = solver.factor(mats)
+        s2 = solver.solve(mats, vecs, g2)
+        torch.cuda.synchronize()
+        ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats.cpu().numpy(), vecs.cpu().numpy())
+        np.testing.assert_array_equal(status.cpu().numpy(), ref_status)
+        np.testing.assert_array_equal(st2.cpu().numpy(), ref_status)
+        ok = ref_status == 0
+        assert ok.sum() == batch - 1
+        for got_s, got_g in ((sol, gains), (s2, g2)):
+            assert _rel(got_s.cpu().numpy()[ok], ref_sol[ok]) <= 1e-9, (n, m)
+            assert _rel(got_g.cpu().numpy()[ok], ref_gains[ok]) <= 1e-9, (n, m)
 
 
 def test_forced_general_engine_equals_fused_kernel(oracle_lib):

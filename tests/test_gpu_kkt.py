@@ -90,7 +90,7 @@ def test_offsets_match_the_reference_ordering():
                                          (16, 4, 10, 8), (13, 5, 6, 4), (20, 3, 5, 3)])
 def test_newton_kkt_benchmark_shapes(n, m, T, batch):
     """Uniform chains (benchmarks/newton_kkt_benchmark.cpp:58-83): packed chain layout; the Riccati
-    part on an exact fused kernel, on an embedding (13,5), or on the general engine (20,3).  n + m > 16
+    part on an exact fused kernel (13,5 among them) or on the general engine (20,3).  n + m > 16
     exercises the multi-tile rank updates of the chain condensation kernel."""
     dims = rk.newton_kkt_dims(n, m, T)
     arrays = rk.newton_kkt_problem(dims, seed=100 * n + m, batch=batch, r2_max=1e2)
