@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--chains", type=int, default=120)
     ap.add_argument("--trees", type=int, default=25)
     ap.add_argument("--kkt", type=int, default=40)
+    ap.add_argument("--max-horizon", type=int, default=13, help="chains: T is drawn from [0, max-horizon]")
+    ap.add_argument("--max-batch", type=int, default=22, help="chains: batch is drawn from [1, max-batch]")
     args = ap.parse_args()
     from oracle import oracle
     from oracle.kkt import KKTDims, KKTOracle
@@ -40,7 +42,7 @@ def main():
 
     for it in range(args.chains):
         n, m = int(rng.integers(1, 19)), int(rng.integers(1, 10))
-        T, batch = int(rng.integers(0, 14)), int(rng.integers(1, 23))
+        T, batch = int(rng.integers(0, args.max_horizon + 1)), int(rng.integers(1, args.max_batch + 1))
         sh = ChainShape(n, m, T)
         mats, vecs = synthetic.make_chain_batch(sh, batch, seed=1000 + it, device="cuda:0", cross_term=0.02)
         bad = None
