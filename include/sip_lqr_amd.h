@@ -16,6 +16,13 @@
  * pointers are ordinary HIP device pointers; `stream` is a hipStream_t
  * passed as void* (NULL = the default stream).  The caller owns every byte
  * (as in the reference: lqr.hpp:136-186, "mem_assign"/"num_bytes").
+ * Device buffers must be 16-byte aligned (hipMalloc and every framework
+ * allocator are; the LDS-DMA kernels return SIP_LQR_ERR_HIP otherwise).
+ * The compute entry points only enqueue kernels on `stream` -- no host
+ * synchronisation, no allocation, no memset / memcpy nodes -- so a loop of
+ * them can be captured in a hipGraph and replayed on any stream (the one
+ * exception is a plan latched INVALID at creation, which reports through a
+ * synchronous copy).
  *
  * ------------------------------------------------------------------------
  * Packed chain layout (device and host-staging buffers; scalar = double for
