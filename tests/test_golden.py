@@ -11,7 +11,6 @@ import numpy as np
 import pytest
 
 import reference_problems as rp
-from oracle import dense_kkt
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CHAINS = sorted(glob.glob(os.path.join(GOLD, "chain_*.npz")))

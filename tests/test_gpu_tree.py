@@ -2,7 +2,6 @@
 reference's own tree fixtures, the oracle and the dense-KKT golden vectors.
 Tolerance: 1e-10 relative l2 per block (the reference's own dense check,
 tests/lqr_test.cpp:995-1010) and KKT residual < 1e-12."""
-import glob
 import os
 
 import numpy as np

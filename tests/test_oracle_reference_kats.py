@@ -6,7 +6,6 @@ integer topology KAT, KKT-residual bounds (< 1e-12) and agreement with a dense
 KKT solve (1e-10, Eigen isApprox = relative l2).  Each test below names the
 reference test it re-expresses.
 """
-import copy
 
 import numpy as np
 import pytest

@@ -4,7 +4,6 @@ against the oracle on random trees.  Host integer work: no GPU needed."""
 import numpy as np
 import pytest
 
-import reference_problems as rp
 
 
 @pytest.fixture(scope="module")
