@@ -20,9 +20,19 @@
  * allocator are; the LDS-DMA kernels return SIP_LQR_ERR_HIP otherwise).
  * The compute entry points only enqueue kernels on `stream` -- no host
  * synchronisation, no allocation, no memset / memcpy nodes -- so a loop of
- * them can be captured in a hipGraph and replayed on any stream (the one
- * exception is a plan latched INVALID at creation, which reports through a
- * synchronous copy).
+ * them can be captured in a hipGraph and replayed on any stream, the first
+ * call on a plan included: everything a plan needs on the device is uploaded
+ * by its *_plan_create (the one exception is a plan latched INVALID at
+ * creation, which reports through a synchronous copy).
+ * Devices: a plan belongs to the HIP device ordinal it was created with.  Every
+ * compute entry point makes that device current for the duration of the call
+ * and restores the caller's current device before it returns, so `stream`
+ * must be a stream of the plan's device (NULL = that device's default stream)
+ * and the buffers must live on it (or be peer-accessible).  *_plan_create
+ * leaves the caller's current device untouched as well.  A chain plan
+ * created on a host without any HIP device serves the host-side entry points
+ * only (sizes, pack / unpack, kernel name); its compute entry points return
+ * SIP_LQR_ERR_HIP.
  *
  * ------------------------------------------------------------------------
  * Packed chain layout (device and host-staging buffers; scalar = double for

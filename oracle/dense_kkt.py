@@ -73,6 +73,47 @@ def solve(parents, children, state_dims, control_dims, blocks, root=0):
     return x, u, y
 
 
+class OffsetFamilies:
+    """The KKT system of one problem, LU-factorised once, solved for modified offsets c[node].
+
+    c[node] enters the right-hand side of one block row only (the initial-state row for the root, the
+    dynamics row of the edge into `node` otherwise).  Used to pin the feedback gains: K_e, k_e of an
+    edge e do not depend on c[j] of any node j that is not a proper descendant of parent(e) -- the
+    backward sweeps (lqr.cpp:645-731, :738-796) reach c[j] only on the way up from j -- so
+    u_e = K_e x_parent(e) + k_e (lqr.cpp:856-857) must hold with the SAME K_e, k_e on every solution
+    of a family that varies c[parent(e)] or the c of an ancestor of it, and dim + 1 affinely
+    independent x_parent(e) determine that affine map completely."""
+
+    def __init__(self, parents, children, state_dims, control_dims, blocks, root=0):
+        import scipy.linalg
+        self.sd, self.cd = list(state_dims), list(control_dims)
+        Kmat, self.rhs, (self.xo, self.uo, self.yo) = assemble(parents, children, state_dims, control_dims,
+                                                               blocks, root)
+        self.lu = scipy.linalg.lu_factor(Kmat)
+        row = sum(state_dims) + sum(control_dims)  # stationarity rows come first (see assemble)
+        self.c_row = {root: row}
+        row += state_dims[root]
+        for e in range(len(control_dims)):
+            self.c_row[children[e]] = row
+            row += state_dims[children[e]]
+
+    def solve(self, node, c_values):
+        """-> list of (x, u, y), one per value of c[node]."""
+        import scipy.linalg
+        B = np.repeat(self.rhs[:, None], len(c_values), axis=1)
+        r = self.c_row[node]
+        for j, c in enumerate(c_values):
+            B[r:r + self.sd[node], j] = -np.asarray(c, dtype=float)
+        Z = scipy.linalg.lu_solve(self.lu, B)
+        out = []
+        for j in range(len(c_values)):
+            z = Z[:, j]
+            out.append(([z[self.xo[i]:self.xo[i] + d] for i, d in enumerate(self.sd)],
+                        [z[self.uo[e]:self.uo[e] + d] for e, d in enumerate(self.cd)],
+                        [z[self.yo[i]:self.yo[i] + d] for i, d in enumerate(self.sd)]))
+        return out
+
+
 def residual_norm(parents, children, state_dims, control_dims, blocks, x, u, y, root=0):
     sq = 0.0
     N, E = len(state_dims), len(control_dims)

@@ -81,6 +81,19 @@ _SIGNATURES = {
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
+
+def resolve_device(device):
+    """torch.device with an explicit ordinal: a bare "cuda" means the CURRENT device (as everywhere in
+    torch), not device 0.  The C ABI launches on the plan's ordinal whatever the caller's current
+    device is (DeviceGuard, csrc/stream_fill.hpp), so buffers, streams and kernels agree."""
+    import torch
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise LQRLibraryError(f"{device!r}: the batched solvers need a HIP device; there is no CPU path")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
 _lib = None
 
 

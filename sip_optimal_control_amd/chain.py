@@ -10,7 +10,7 @@ import enum
 
 import torch
 
-from ._lib import LQRLibraryError, load_library
+from ._lib import LQRLibraryError, load_library, resolve_device
 from .layout import ChainShape
 
 
@@ -41,12 +41,10 @@ class BatchedChainLQR:
         self.shape = ChainShape(n, m, T)
         self.batch = int(batch)
         self.dtype = dtype
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise LQRLibraryError("BatchedChainLQR needs a HIP device; there is no CPU path")
+        self.device = resolve_device(device)  # explicit ordinal; raises without a HIP device
         handle = ctypes.c_void_p()
         _check(self._lib.sip_lqr_plan_create(_DTYPES[dtype], self.batch, T, n, m,
-                                             self.device.index or 0, ctypes.byref(handle)),
+                                             self.device.index, ctypes.byref(handle)),
                f"sip_lqr_plan_create(n={n}, m={m}, T={T}, {dtype})")
         self._plan = handle
         esize = torch.empty((), dtype=dtype).element_size()

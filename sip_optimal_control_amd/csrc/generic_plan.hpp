@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "stream_fill.hpp"
 #include "tree_generic.hpp"
 #include "tree_lds.hpp"
 
@@ -158,7 +159,8 @@ struct GenericPlan {
       at.push_back(longs.size());
       longs.insert(longs.end(), t->begin(), t->end());
     }
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard on_device(device); // the caller's current device is restored on return
+    hipError_t e = on_device.err;
     if (e != hipSuccess) return e;
     if ((e = hipMalloc(&d_ints, std::max<size_t>(1, ints.size()) * sizeof(int))) != hipSuccess) return e;
     if ((e = hipMalloc(&d_longs, std::max<size_t>(1, longs.size()) * sizeof(long))) != hipSuccess) return e;

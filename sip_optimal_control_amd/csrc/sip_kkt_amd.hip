@@ -459,7 +459,8 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
   for (int t = 0; t < 12; ++t)
     a_l[t] = pl(*lq[t]);
 
-  hipError_t he = hipSetDevice(device);
+  sipamd::DeviceGuard on_device(device); // the caller's current device is restored on return
+  hipError_t he = on_device.err;
   if (he == hipSuccess)
     he = hipMalloc(&p->d_ints, std::max<size_t>(1, ints.size()) * sizeof(int));
   if (he == hipSuccess)
@@ -536,6 +537,9 @@ int sip_kkt_factor(const sip_kkt_plan *p, const double *d_model, const double *d
                    const double *d_r2, const double *d_r3, void *d_work, int32_t *d_status, void *stream) {
   if (p == nullptr || d_status == nullptr)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_kkt_factor(hipSetDevice)");
   hipStream_t s = (hipStream_t)stream;
   if (p->input_status != SIP_KKT_SUCCESS)
     return fill_status(p, d_status, s);
@@ -562,6 +566,9 @@ int sip_kkt_solve(const sip_kkt_plan *p, const double *d_model, const double *d_
   const long kkt = (long)p->x_dim + p->y_dim + p->z_dim;
   if ((!d_model && p->model_len > 0) || (kkt > 0 && (!d_b || !d_sol)) || !d_work)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_kkt_solve(hipSetDevice)");
   hipStream_t s = (hipStream_t)stream;
   const Regions r = regions(p, d_work);
   hipError_t e = launch_rhs(p, r, d_model, d_b, d_status, s);
@@ -587,6 +594,9 @@ int sip_kkt_factor_solve(const sip_kkt_plan *p, const double *d_model, const dou
   if (!d_model || (!d_w && p->z_dim > 0) || !d_r1 || !d_r2 || (!d_r3 && p->z_dim > 0) || !d_work ||
       (kkt > 0 && (!d_b || !d_sol)))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_kkt_factor_solve(hipSetDevice)");
   hipStream_t s = (hipStream_t)stream;
   const Regions r = regions(p, d_work);
   const bool fused_rhs = p->staged || p->chain_kernels;
@@ -614,6 +624,9 @@ int sip_kkt_add_Kx_to_y(const sip_kkt_plan *p, const double *d_model, const doub
   if ((!d_model && p->model_len > 0) || (!d_w && p->z_dim > 0) || (!d_r1 && p->x_dim > 0) ||
       (!d_r2 && p->y_dim > 0) || (!d_r3 && p->z_dim > 0) || !d_x || !d_y)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_kkt_add_Kx_to_y(hipSetDevice)");
   if (p->chain_kernels)
     hipLaunchKernelGGL(sipamd::kkt::apply_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
                        p->lds_chain_apply, (hipStream_t)stream, p->ck, 0, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y,
@@ -683,7 +696,8 @@ int sip_kkt_plan_set_theta(sip_kkt_plan *p, int theta_dim) {
     where[b] = longs.size();
     longs.insert(longs.end(), p->toff[b].begin(), p->toff[b].end());
   }
-  hipError_t he = hipSetDevice(p->device);
+  sipamd::DeviceGuard on_device(p->device);
+  hipError_t he = on_device.err;
   if (he == hipSuccess)
     he = hipMalloc(&p->d_theta_longs, longs.size() * sizeof(long));
   if (he == hipSuccess)
@@ -722,13 +736,19 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   // r1 of problem q starts at q * (x_dim + p); the condensation kernels index r1 with the
   // stagewise stride x_dim, so they get a compacted copy (theta entries dropped).
+  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_kkt_factor_theta(hipSetDevice)");
   hipStream_t s = (hipStream_t)stream;
   const ThetaRegions t = theta_regions(p, d_theta_work);
   const int sx = p->x_dim, th = p->theta_dim;
   const long skkt = (long)sx + p->y_dim + p->z_dim;
   // compact r1 (drop the theta entries) into rhs_sw's space (free until solve)
-  hipError_t e = hipMemcpy2DAsync(t.rhs_sw, sizeof(double) * (size_t)sx, d_r1, sizeof(double) * (size_t)(sx + th),
-                                  sizeof(double) * (size_t)sx, (size_t)p->batch, hipMemcpyDeviceToDevice, s);
+  // (a kernel, not a memcpy node: the entry points stay graph-capturable, stream_fill.hpp)
+  if (sx > 0)
+    hipLaunchKernelGGL(sipamd::kkt::theta_strip_kernel, dim3((unsigned)((p->batch * (long)sx + 255) / 256)), dim3(256), 0,
+                       s, d_r1, t.rhs_sw, sx, th, (long)sx, (long)p->batch);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return report(e, "sip_kkt_factor_theta(r1)");
   int rc = sip_kkt_factor(p, d_model, d_w, t.rhs_sw, d_r2, d_r3, d_work, d_status, stream);
@@ -783,6 +803,9 @@ int sip_kkt_solve_theta(const sip_kkt_plan *p, const double *d_model, const doub
                         double *d_sol, void *d_work, void *d_theta_work, const int32_t *d_status, void *stream) {
   if (p == nullptr || p->theta_dim < 1 || !d_theta || !d_theta_work || !d_b || !d_sol || !d_status)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_kkt_solve_theta(hipSetDevice)");
   hipStream_t s = (hipStream_t)stream;
   const ThetaRegions t = theta_regions(p, d_theta_work);
   const int sx = p->x_dim, th = p->theta_dim;
@@ -806,6 +829,9 @@ int sip_kkt_add_Kx_to_y_theta(const sip_kkt_plan *p, const double *d_model, cons
                               const double *d_x, double *d_y, void *stream) {
   if (p == nullptr || p->theta_dim < 1 || !d_theta || !d_r1 || !d_x || !d_y)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_kkt_add_Kx_to_y_theta(hipSetDevice)");
   hipStream_t s = (hipStream_t)stream;
   if (p->chain_kernels) {
     hipLaunchKernelGGL(sipamd::kkt::apply_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),

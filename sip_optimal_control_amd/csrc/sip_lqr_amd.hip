@@ -30,9 +30,12 @@ struct sip_lqr_plan {
   sipamd::launch_fs_t launch_fs;
   // General engine on the packed chain layout: serves shapes / dtypes without
   // a dedicated kernel and the split factor / solve entry points.  Tables are
-  // laid out at plan creation (host only), uploaded at first use.
-  mutable sipamd::GenericPlan gen;
-  mutable bool gen_uploaded = false;
+  // laid out and uploaded at plan creation, so that the compute entry points
+  // only enqueue kernels (graph-capturable from the first call on).
+  sipamd::GenericPlan gen;
+  // false: the plan was created on a host without a HIP device and serves the
+  // host-side entry points only (sizes, pack / unpack, kernel name).
+  bool on_device = false;
   // Split factor / solve of a shape with a fused kernel: both re-run the fused sweep (factor on a
   // zero right-hand side), which beats a second, slower kernel family by an order of magnitude;
   // SIP_LQR_SPLIT=general keeps them on the general engine.
@@ -46,6 +49,10 @@ struct sip_lqr_plan {
   bool solve_only = false; // the kernel has the vector-only solve mode (qw16)
   std::string name_storage;
 };
+
+// Overridden by the object __graft_entry__.build_hip() generates (build_stamp.c); a library linked
+// without it (tools/diag_build.sh) says so.
+extern "C" __attribute__((weak)) const char sip_lqr_build_stamp[] = "SIPLQRSRC=unstamped";
 
 #ifdef SIP_LQR_STAMPS
 // Diagnostic build: device buffer of 8 x u64 per wave, set by the tool.
@@ -166,14 +173,8 @@ void init_generic(sip_lqr_plan *p) {
   g.layout_chain(p->n, p->m, T);
 }
 
-hipError_t ensure_generic(const sip_lqr_plan *p) {
-  if (p->gen_uploaded)
-    return hipSuccess;
-  const hipError_t e = p->gen.upload(p->device);
-  if (e == hipSuccess)
-    p->gen_uploaded = true;
-  return e;
-}
+// Compute entry points: the plan must live on a device (see sip_lqr_plan::on_device).
+hipError_t require_device(const sip_lqr_plan *p) { return p->on_device ? hipSuccess : hipErrorNoDevice; }
 
 // Bytes of the general engine's work arena, plus the status copy it keeps for
 // sip_lqr_solve (which has no status argument).
@@ -410,6 +411,27 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
   const char *split = std::getenv("SIP_LQR_SPLIT");
   p->split_on_fused = p->launch_fs != nullptr && !(split && std::strcmp(split, "general") == 0);
   init_generic(p);
+  // Device tables of the general engine: uploaded here, never lazily (include/sip_lqr_amd.h
+  // promises that the compute entry points neither allocate nor synchronise).  A host without any
+  // HIP device still gets a plan for the host-side entry points.
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess)
+    ndev = 0;
+  if (ndev > 0) {
+    if (device < 0 || device >= ndev) {
+      delete p;
+      return SIP_LQR_ERR_INVALID_ARGUMENT;
+    }
+    const hipError_t e = p->gen.upload(device); // restores the caller's current device
+    if (e != hipSuccess) {
+      std::fprintf(stderr, "sip_lqr_plan_create: HIP error: %s\n", hipGetErrorString(e));
+      delete p;
+      return SIP_LQR_ERR_HIP;
+    }
+    p->on_device = true;
+  } else {
+    (void)hipGetLastError(); // hipErrorNoDevice is not sticky for the caller
+  }
   *plan = p;
   return SIP_LQR_OK;
 }
@@ -567,11 +589,16 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
       !d_workspace || (plan->T > 0 && !d_gains))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
+  if (require_device(plan) != hipSuccess)
+    return report(hipErrorNoDevice, "sip_lqr_factor_solve");
+  sipamd::DeviceGuard on_device(plan->device);
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_lqr_factor_solve(hipSetDevice)");
   if (plan->launch_fs != nullptr)
     return report(run_fused(plan, d_mats, d_vecs, d_sol, d_gains, d_status, d_workspace, s, 0),
                   "sip_lqr_factor_solve");
   // no dedicated kernel for this shape / dtype: general engine, two launches
-  hipError_t e = ensure_generic(plan);
+  hipError_t e = hipSuccess;
   if (e == hipSuccess)
     e = plan->dtype == SIP_LQR_F32
             ? plan->gen.launch_factor<float>(plan->batch, d_mats, d_workspace, d_gains, d_status, s)
@@ -590,6 +617,11 @@ int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
   if (plan == nullptr || !d_mats || !d_status || !d_workspace || (plan->T > 0 && !d_gains))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
+  if (require_device(plan) != hipSuccess)
+    return report(hipErrorNoDevice, "sip_lqr_factor");
+  sipamd::DeviceGuard on_device(plan->device);
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_lqr_factor(hipSetDevice)");
   if (plan->split_on_fused) { // fused sweep on a zero right-hand side: K, statuses
     const FusedSplit f = fused_split_layout(plan);
     char *w = (char *)d_workspace;
@@ -598,7 +630,7 @@ int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,
       e = sipamd::copy_async(w + f.status, d_status, (size_t)plan->batch * sizeof(int32_t), s);
     return report(e, "sip_lqr_factor(fused)");
   }
-  hipError_t e = ensure_generic(plan);
+  hipError_t e = hipSuccess;
   if (e == hipSuccess)
     e = plan->dtype == SIP_LQR_F32
             ? plan->gen.launch_factor<float>(plan->batch, d_mats, d_workspace, d_gains, d_status, s)
@@ -613,13 +645,18 @@ int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats, const void *d_ve
   if (plan == nullptr || !d_mats || !d_vecs || !d_sol || !d_workspace || (plan->T > 0 && !d_gains))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
+  if (require_device(plan) != hipSuccess)
+    return report(hipErrorNoDevice, "sip_lqr_solve");
+  sipamd::DeviceGuard on_device(plan->device);
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_lqr_solve(hipSetDevice)");
   if (plan->split_on_fused) { // the fused sweep again, now with the right-hand side
     const FusedSplit f = fused_split_layout(plan);
     return report(run_fused(plan, d_mats, d_vecs, d_sol, d_gains, (int32_t *)((char *)d_workspace + f.status),
                             d_workspace, s, 2),
                   "sip_lqr_solve(fused)");
   }
-  hipError_t e = ensure_generic(plan);
+  hipError_t e = hipSuccess;
   const int32_t *st = generic_status(plan, d_workspace);
   if (e == hipSuccess)
     e = plan->dtype == SIP_LQR_F32
@@ -632,6 +669,12 @@ const char *sip_lqr_kernel_name(const sip_lqr_plan *plan) {
   return plan ? plan->kernel_name : "";
 }
 
-const char *sip_lqr_version(void) { return "sip_lqr_amd 0.1 (gfx950)"; }
+// "sip_lqr_amd <version> (gfx950) SIPLQRSRC=<sha256 of the sources and flags the library was built
+// from>": __graft_entry__.build_hip() links the stamp in and rebuilds when it differs from the sources
+// next to the library; bench.py and smoke() print it, so that a run record names the build it measured.
+const char *sip_lqr_version(void) {
+  static const std::string v = std::string("sip_lqr_amd 0.2 (gfx950) ") + sip_lqr_build_stamp;
+  return v.c_str();
+}
 
 } // extern "C"

@@ -65,13 +65,24 @@ int sip_lqr_group_all_gather_gains(sip_lqr_group *g, const sip_lqr_plan *const *
       return SIP_LQR_ERR_INVALID_ARGUMENT; // equal shards: the batch is block-partitioned evenly
   if (bytes == 0)
     return SIP_LQR_OK;
+  int prev_device = -1;
+  (void)hipGetDevice(&prev_device); // restored below: the loop visits every rank's device
   ncclResult_t r = ncclGroupStart();
-  for (int i = 0; i < n && r == ncclSuccess; ++i) {
-    if (hipSetDevice(g->devices[i]) != hipSuccess)
-      return SIP_LQR_ERR_HIP;
+  bool hip_failed = false;
+  // No early return between ncclGroupStart and ncclGroupEnd: an open group would swallow every
+  // later collective of this thread.
+  for (int i = 0; i < n && r == ncclSuccess && !hip_failed; ++i) {
+    if (hipSetDevice(g->devices[i]) != hipSuccess) {
+      hip_failed = true;
+      break;
+    }
     r = ncclAllGather(d_gains[i], d_all_gains[i], bytes, ncclChar, g->comms[i], (hipStream_t)streams[i]);
   }
   const ncclResult_t e = ncclGroupEnd();
+  if (prev_device >= 0)
+    (void)hipSetDevice(prev_device);
+  if (hip_failed)
+    return SIP_LQR_ERR_HIP;
   if (r != ncclSuccess)
     return fail("sip_lqr_group_all_gather_gains(ncclAllGather)", r);
   return e == ncclSuccess ? SIP_LQR_OK : fail("sip_lqr_group_all_gather_gains(ncclGroupEnd)", e);

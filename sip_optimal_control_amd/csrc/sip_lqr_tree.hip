@@ -152,6 +152,9 @@ int sip_lqr_tree_factor(const sip_lqr_tree_plan *plan, const double *d_input,
   if (plan == nullptr || d_status == nullptr)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
+  sipamd::DeviceGuard on_device(plan->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return SIP_LQR_ERR_HIP;
   if (plan->topology_status != SIP_LQR_SUCCESS) {
     // every instance reports the latched traversal status (lqr.cpp:646-648)
     std::vector<int32_t> st((size_t)plan->batch, plan->topology_status);
@@ -178,6 +181,9 @@ int sip_lqr_tree_solve(const sip_lqr_tree_plan *plan, const double *d_input,
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   if (plan->topology_status != SIP_LQR_SUCCESS)
     return SIP_LQR_ERR_INVALID_ARGUMENT; // solve() needs a successful factor
+  sipamd::DeviceGuard on_device(plan->device);
+  if (on_device.err != hipSuccess)
+    return SIP_LQR_ERR_HIP;
   const hipError_t e = plan->g.launch_solve<double>((long)plan->batch, d_input, d_input, d_work, d_work,
                                                     d_output, d_status, (hipStream_t)stream);
   if (e != hipSuccess) {

@@ -14,6 +14,29 @@
 
 namespace sipamd {
 
+// Makes `device` the calling thread's current HIP device for the lifetime of the guard and restores
+// the previous one afterwards.  Every compute entry point of the C ABI holds one: a plan launches on
+// ITS device whatever the caller's current device is (a NULL stream then means that device's default
+// stream), and the caller's current device is left as it was found.  hipSetDevice is thread-local
+// state, not a stream operation, so it is legal during stream capture.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device)
+      err = hipSetDevice(device);
+    else if (err == hipSuccess)
+      prev = -1; // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0)
+      (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // 4-byte words (every region filled or copied here is int32 / float / double data, 4-byte aligned)
 static __global__ void __launch_bounds__(256) fill_zero_kernel(uint32_t *__restrict__ dst, long words) {
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < words; k += (long)gridDim.x * blockDim.x)

@@ -12,7 +12,7 @@ import ctypes
 
 import torch
 
-from ._lib import LQRLibraryError, load_library
+from ._lib import LQRLibraryError, load_library, resolve_device
 from .chain import _check
 
 NODE_BLOCKS = ("d2L_dx2", "dc_dx", "dg_dx")
@@ -32,15 +32,13 @@ class BatchedNewtonKKT:
     def __init__(self, parents, children, state_dims, control_dims, node_c_dims=None, node_g_dims=None,
                  edge_c_dims=None, edge_g_dims=None, batch=1, root=0, device="cuda:0", theta_dim=0):
         self._lib = load_library()
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise LQRLibraryError("BatchedNewtonKKT needs a HIP device; there is no CPU path")
+        self.device = resolve_device(device)  # explicit ordinal; raises without a HIP device
         self.E, self.N, self.batch = len(control_dims), len(control_dims) + 1, int(batch)
         h = ctypes.c_void_p()
         _check(self._lib.sip_kkt_plan_create(self.batch, self.E, root, _ints(parents), _ints(children),
                                              _ints(state_dims), _ints(control_dims), _ints(node_c_dims),
                                              _ints(node_g_dims), _ints(edge_c_dims), _ints(edge_g_dims),
-                                             self.device.index or 0, ctypes.byref(h)), "sip_kkt_plan_create")
+                                             self.device.index, ctypes.byref(h)), "sip_kkt_plan_create")
         self._plan = h
         self.input_status = self._lib.sip_kkt_input_status(h)
         self.x_dim, self.y_dim, self.z_dim, self.model_len = (self._lib.sip_kkt_len(h, k) for k in range(4))

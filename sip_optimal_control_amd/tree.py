@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import LQRLibraryError, load_library
+from ._lib import LQRLibraryError, load_library, resolve_device
 from .chain import _check
 
 _NODE_IN = ("Q", "q", "c", "delta")
@@ -42,13 +42,11 @@ class BatchedTreeLQR:
         self.parents, self.children = list(parents), list(children)
         self.state_dims, self.control_dims = list(state_dims), list(control_dims)
         self.batch = int(batch)
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise LQRLibraryError("BatchedTreeLQR needs a HIP device; there is no CPU path")
+        self.device = resolve_device(device)  # explicit ordinal; raises without a HIP device
         h = ctypes.c_void_p()
         _check(self._lib.sip_lqr_tree_plan_create(self.batch, self.E, root, _ints(self.parents),
                                                   _ints(self.children), _ints(self.state_dims),
-                                                  _ints(self.control_dims), self.device.index or 0,
+                                                  _ints(self.control_dims), self.device.index,
                                                   ctypes.byref(h)), "sip_lqr_tree_plan_create")
         self._plan = h
         self.topology_status = self._lib.sip_lqr_tree_topology_status(h)

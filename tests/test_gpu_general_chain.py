@@ -215,3 +215,50 @@ def test_randomized_stress_sample():
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
     assert "0 failures" in proc.stdout
+
+
+def test_first_call_of_a_general_engine_plan_can_be_the_captured_one(oracle_lib):
+    """include/sip_lqr_amd.h: the compute entry points only enqueue kernels.  The general engine's
+    offset tables are uploaded by sip_lqr_plan_create (not lazily at first use), so the very first
+    factor_solve of a plan may run under stream capture; replaying the graph gives the oracle's
+    result.  (The code object is loaded beforehand by another plan of the same engine.)"""
+    from sip_optimal_control_amd import BatchedChainLQR
+    n, m, T, batch = 19, 3, 9, 7
+    mats, vecs = _make(n, m, T, batch, seed=91)
+    warm = BatchedChainLQR(n, m, T, batch)
+    assert "tree_generic" in warm.kernel_name
+    warm.factor_solve(mats, vecs)
+    torch.cuda.synchronize()
+    solver = BatchedChainLQR(n, m, T, batch)          # a fresh plan: nothing of it has run yet
+    sol, gains = solver.empty_sol().zero_(), solver.empty_gains().zero_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        solver.factor_solve(mats, vecs, sol, gains)
+    torch.cuda.synchronize()
+    assert float(sol.abs().max()) == 0.0               # captured, not executed
+    graph.replay()
+    torch.cuda.synchronize()
+    ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats.cpu().numpy(), vecs.cpu().numpy())
+    np.testing.assert_array_equal(solver.status.cpu().numpy(), ref_status)
+    assert _rel(sol.cpu().numpy(), ref_sol) <= 1e-9 and _rel(gains.cpu().numpy(), ref_gains) <= 1e-9
+
+
+def test_plan_device_is_explicit_and_left_alone(oracle_lib):
+    """A bare "cuda" means torch's current device (not device 0), the plan launches on its own
+    ordinal (DeviceGuard in the C ABI) and the caller's current device is what it was."""
+    from sip_optimal_control_amd import BatchedChainLQR
+    from sip_optimal_control_amd._lib import LQRLibraryError, resolve_device
+    cur = torch.cuda.current_device()
+    assert resolve_device("cuda") == torch.device("cuda", cur)
+    solver = BatchedChainLQR(4, 2, 5, 3, device="cuda")
+    assert solver.device.index == cur
+    mats, vecs = _make(4, 2, 5, 3, seed=12)
+    sol, _, status = solver.factor_solve(mats, vecs)
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == cur
+    ref_sol, _, _ = oracle_lib.chain_batch(4, 2, 5, mats.cpu().numpy(), vecs.cpu().numpy())
+    assert _rel(sol.cpu().numpy(), ref_sol) <= 1e-9
+    with pytest.raises(LQRLibraryError):               # an ordinal the machine does not have
+        BatchedChainLQR(4, 2, 5, 3, device=f"cuda:{torch.cuda.device_count()}")

@@ -72,10 +72,9 @@ def test_shipped_kernels_are_hazard_free():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as entry
     pattern = os.path.join(ROOT, "build", "obj", "*", "*-hip-amdgcn-amd-amdhsa-gfx950.s")
-    lib = entry.build_hip()
-    stale = [p for p in glob.glob(pattern) if os.path.getmtime(p) > os.path.getmtime(lib)]
-    if len(glob.glob(pattern)) < 3 + entry.QW16_SLICES or stale:  # library from elsewhere: rebuild with listings
-        entry.build_hip(force=True)
+    entry.build_hip()
+    if len(glob.glob(pattern)) < 3 + entry.QW16_SLICES or not entry.listings_current():
+        entry.build_hip(force=True)  # library from elsewhere (no build/obj): rebuild with listings
     listings = sorted(glob.glob(pattern))
     units = {os.path.basename(os.path.dirname(p)) for p in listings}
     assert {"sip_lqr_amd"} | {"qw16_extra_%d" % k for k in range(entry.QW16_SLICES)} <= units
