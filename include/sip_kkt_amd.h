@@ -10,7 +10,14 @@
  *   solve(b, sol)           helpers.cpp:749-893   -> sip_kkt_solve
  *   factor + solve          newton_kkt_benchmark.cpp:316-324 (loop body of
  *                           BM_NewtonKKTFactorSolve)  -> sip_kkt_factor_solve
- *   add_Kx_to_y(...)        helpers.cpp:953-1368  -> sip_kkt_add_Kx_to_y
+ *   add_Kx_to_y(...)        helpers.cpp:953-976   -> sip_kkt_add_Kx_to_y
+ *   add_Hx_to_y(x, y)       helpers.cpp:978-1067  -> sip_kkt_add_Hx_to_y
+ *   add_Cx_to_y(x, y)       helpers.cpp:1069-1159 -> sip_kkt_add_Cx_to_y
+ *   add_CTx_to_y(x, y)      helpers.cpp:1161-1250 -> sip_kkt_add_CTx_to_y
+ *   add_Gx_to_y(x, y)       helpers.cpp:1252-1309 -> sip_kkt_add_Gx_to_y
+ *   add_GTx_to_y(x, y)      helpers.cpp:1311-1368 -> sip_kkt_add_GTx_to_y
+ *                           (the callbacks SIP is handed one by one,
+ *                           sip_optimal_control.cpp:147-190)
  * The Riccati solve in the middle is the library's own LQR path
  * (sip_lqr_amd.h): uniform chains use the packed chain layout and its fused
  * kernels, everything else the general tree engine.
@@ -159,6 +166,28 @@ int sip_kkt_add_Kx_to_y(const sip_kkt_plan *plan, const double *d_model,
                         const double *d_r2, const double *d_r3,
                         const double *d_x, double *d_y, void *stream);
 
+/* Replace CallbackProvider::add_Hx_to_y / add_Cx_to_y / add_CTx_to_y /
+ * add_Gx_to_y / add_GTx_to_y (helpers.hpp:20-24; bodies helpers.cpp:978-1368):
+ * y += (block) x for one block of K, for every problem of the batch.  Unlike
+ * add_Kx_to_y the vectors are per vector space, [batch][len] contiguous:
+ *   x-space: the primal variables, len = sip_kkt_len(SIP_KKT_LEN_X)
+ *   y-space: the equality multipliers, len = sip_kkt_len(SIP_KKT_LEN_Y)
+ *   z-space: the inequality multipliers, len = sip_kkt_len(SIP_KKT_LEN_Z)
+ *     Hx : x-space -> x-space      Cx : x-space -> y-space     CTx: y-space -> x-space
+ *     Gx : x-space -> z-space      GTx: z-space -> x-space
+ * A block with an empty space is a no-op.  add_Kx_to_y is their sum plus the
+ * regularization diagonal (helpers.cpp:958-975). */
+int sip_kkt_add_Hx_to_y(const sip_kkt_plan *plan, const double *d_model,
+                        const double *d_x, double *d_y, void *stream);
+int sip_kkt_add_Cx_to_y(const sip_kkt_plan *plan, const double *d_model,
+                        const double *d_x, double *d_y, void *stream);
+int sip_kkt_add_CTx_to_y(const sip_kkt_plan *plan, const double *d_model,
+                         const double *d_x, double *d_y, void *stream);
+int sip_kkt_add_Gx_to_y(const sip_kkt_plan *plan, const double *d_model,
+                        const double *d_x, double *d_y, void *stream);
+int sip_kkt_add_GTx_to_y(const sip_kkt_plan *plan, const double *d_model,
+                         const double *d_x, double *d_y, void *stream);
+
 /* ------------------------------------------------------------------------
  * Global variables theta (Dimensions::theta_dim = p > 0; SURVEY.md section 8
  * row f2): the Schur complement on theta around the stagewise solve.
@@ -215,6 +244,26 @@ int sip_kkt_add_Kx_to_y_theta(const sip_kkt_plan *plan, const double *d_model,
                               const double *d_r1, const double *d_r2,
                               const double *d_r3, const double *d_x,
                               double *d_y, void *stream);
+
+/* The five block operators with theta: x-space vectors are [stagewise x |
+ * theta] (len = sip_kkt_len(SIP_KKT_LEN_X) + theta_dim) and the theta sections
+ * of the reference's bodies are included (helpers.cpp:1023-1066, 1128-1158,
+ * 1221-1249, 1285-1308, 1344-1367). */
+int sip_kkt_add_Hx_to_y_theta(const sip_kkt_plan *plan, const double *d_model,
+                              const double *d_theta_model, const double *d_x,
+                              double *d_y, void *stream);
+int sip_kkt_add_Cx_to_y_theta(const sip_kkt_plan *plan, const double *d_model,
+                              const double *d_theta_model, const double *d_x,
+                              double *d_y, void *stream);
+int sip_kkt_add_CTx_to_y_theta(const sip_kkt_plan *plan, const double *d_model,
+                               const double *d_theta_model, const double *d_x,
+                               double *d_y, void *stream);
+int sip_kkt_add_Gx_to_y_theta(const sip_kkt_plan *plan, const double *d_model,
+                              const double *d_theta_model, const double *d_x,
+                              double *d_y, void *stream);
+int sip_kkt_add_GTx_to_y_theta(const sip_kkt_plan *plan, const double *d_model,
+                               const double *d_theta_model, const double *d_x,
+                               double *d_y, void *stream);
 
 #ifdef __cplusplus
 }

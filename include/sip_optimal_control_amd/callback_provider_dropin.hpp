@@ -250,7 +250,39 @@ public:
     std::copy(y.begin() + sx_ + p_ + y_, y.begin() + full_, y_z);
   }
 
+  // helpers.hpp:20-24, bodies helpers.cpp:978-1368: the block operators SIP is handed one by one
+  // (sip_optimal_control.cpp:147-190).  x-space vectors have x_dim entries (theta included),
+  // y-space y_dim, z-space z_dim; every one accumulates into y.
+  void add_Hx_to_y(const double *x, double *y) { block_op(0, x, sx_ + p_, y, sx_ + p_); }
+  void add_Cx_to_y(const double *x, double *y) { block_op(1, x, sx_ + p_, y, y_); }
+  void add_CTx_to_y(const double *x, double *y) { block_op(2, x, y_, y, sx_ + p_); }
+  void add_Gx_to_y(const double *x, double *y) { block_op(3, x, sx_ + p_, y, z_); }
+  void add_GTx_to_y(const double *x, double *y) { block_op(4, x, z_, y, sx_ + p_); }
+
 private:
+  void block_op(int which, const double *x, int x_len, double *y, int y_len) {
+    typedef int (*plain_fn)(const sip_kkt_plan *, const double *, const double *, double *, void *);
+    typedef int (*theta_fn)(const sip_kkt_plan *, const double *, const double *, const double *, double *, void *);
+    static const plain_fn plain[5] = {sip_kkt_add_Hx_to_y, sip_kkt_add_Cx_to_y, sip_kkt_add_CTx_to_y,
+                                      sip_kkt_add_Gx_to_y, sip_kkt_add_GTx_to_y};
+    static const theta_fn with_theta[5] = {sip_kkt_add_Hx_to_y_theta, sip_kkt_add_Cx_to_y_theta,
+                                           sip_kkt_add_CTx_to_y_theta, sip_kkt_add_Gx_to_y_theta,
+                                           sip_kkt_add_GTx_to_y_theta};
+    if (!input_is_valid_ || x_len == 0 || y_len == 0)
+      return;
+    gather_model(); // the callback outputs may have changed since the last call (helpers.cpp reads them live)
+    up(d_model_, model_.data(), model_.size());
+    up(d_a_, x, x_len), up(d_b_, y, y_len);
+    int rc;
+    if (p_ > 0) {
+      up(d_theta_, theta_.data(), theta_.size());
+      rc = with_theta[which](plan_, d_model_, d_theta_, d_a_, d_b_, nullptr);
+    } else {
+      rc = plain[which](plan_, d_model_, d_a_, d_b_, nullptr);
+    }
+    check(rc == SIP_LQR_OK, "sip_kkt_add_*x_to_y");
+    down(y, d_b_, y_len);
+  }
   static void check(bool ok, const char *what) {
     if (!ok) {
       std::fprintf(stderr, "sip_optimal_control_amd: %s failed (this adapter needs libsip_lqr_amd.so and a HIP device)\n",

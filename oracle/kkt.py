@@ -62,6 +62,10 @@ def _lib():
         L.kkt_oracle_solve_theta.restype = None
         L.kkt_oracle_add_Kx_to_y_theta.argtypes = [ctypes.c_void_p] * 9
         L.kkt_oracle_add_Kx_to_y_theta.restype = None
+        for name in ("Hx", "Cx", "CTx", "Gx", "GTx"):
+            fn = getattr(L, f"kkt_oracle_add_{name}_to_y")
+            fn.argtypes = [ctypes.c_void_p] * 5
+            fn.restype = None
         L.kkt_oracle_batch.argtypes = [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_void_p] * 8 + [ctypes.c_int]
         _ready = True
     return L
@@ -212,7 +216,12 @@ class KKTDims:
         return nodes, edges
 
 
-def dense_kkt_matrix(dims, model, w, r1, r2, r3, theta_model=None):
+def dense_kkt_blocks(dims, model, theta_model=None):
+    """The blocks H, C, G of the KKT matrix (x-space columns: [stagewise x | theta])."""
+    return dense_kkt_matrix(dims, model, None, None, None, None, theta_model, blocks_only=True)
+
+
+def dense_kkt_matrix(dims, model, w, r1, r2, r3, theta_model=None, blocks_only=False):
     """Full regularized KKT matrix from the model blocks (independent of the C code)."""
     nodes, edges = dims.unpack_model(model)
     xd, yd, zd = dims.x_dim, dims.y_dim, dims.z_dim
@@ -275,6 +284,8 @@ def dense_kkt_matrix(dims, model, w, r1, r2, r3, theta_model=None):
             Cf[sl(o["y_edge_c"][e], dims.ecd[e]), th] += te[e]["dc_dtheta"]
             Gf[sl(o["z_edge"][e], dims.egd[e]), th] += te[e]["dg_dtheta"]
         H, C, G, xd = Hf, Cf, Gf, xd + p
+    if blocks_only:
+        return H, C, G
     K = np.zeros((xd + yd + zd, xd + yd + zd))
     K[:xd, :xd] = H + np.diag(r1)
     K[:xd, xd:xd + yd] = C.T
@@ -341,6 +352,23 @@ class KKTOracle:
         keep = [_f64(a) for a in (model, w, r1, r2, r3, x)]
         out = np.zeros(self.dims.kkt_dim) if y is None else np.array(y, dtype=np.float64)
         _lib().kkt_oracle_add_Kx_to_y(self.h, *[k[1] for k in keep], out.ctypes.data)
+        return out
+
+    # the five block operators (helpers.hpp:20-24): (input space, output space) of each
+    BLOCK_SPACES = {"Hx": ("x", "x"), "Cx": ("x", "y"), "CTx": ("y", "x"), "Gx": ("x", "z"), "GTx": ("z", "x")}
+
+    def space_dim(self, space):
+        d = self.dims
+        return {"x": d.x_dim + d.p, "y": d.y_dim, "z": d.z_dim}[space]
+
+    def add_block_to_y(self, name, model, x, y=None, theta_model=None):
+        """y += (block) x for name in BLOCK_SPACES; x-space vectors are [stagewise x | theta]."""
+        src, dst = self.BLOCK_SPACES[name]
+        keep = [_f64(model), _f64(x)]
+        assert keep[1][0].size == self.space_dim(src)
+        tm = _f64(theta_model) if theta_model is not None else (None, None)
+        out = np.zeros(self.space_dim(dst)) if y is None else np.array(y, dtype=np.float64)
+        getattr(_lib(), f"kkt_oracle_add_{name}_to_y")(self.h, keep[0][1], tm[1], keep[1][1], out.ctypes.data)
         return out
 
     def lqr_block(self, name, index, size):

@@ -867,3 +867,161 @@ void kkt_oracle_add_Kx_to_y_theta(const kkt_oracle *o, const double *model, cons
   for (int d = 0; d < p; ++d) /* r1 on the theta block, :965-967 */
     y_theta[d] += r1[sx + d] * theta[d];
 }
+
+/* ------------------------------------------------------------------------
+ * The five block operators CallbackProvider hands to SIP one by one
+ * (sip_optimal_control.cpp:147-190), each restated from its own body; theta
+ * sections included when o->p > 0 (tm: the theta arena; x-space vectors are
+ * then [stagewise x | theta]).  kkt_oracle_add_Kx_to_y above is their
+ * composition plus the regularization diagonal (helpers.cpp:953-976), which
+ * tests/test_kkt_oracle_reference.py checks.
+ * ------------------------------------------------------------------------ */
+
+/* CallbackProvider::add_Hx_to_y, helpers.cpp:978-1067: x, y in x-space. */
+void kkt_oracle_add_Hx_to_y(const kkt_oracle *o, const double *model, const double *tm,
+                            const double *x, double *y) {
+  const int E = o->E, N = o->N, p = o->p, sx = o->x_dim;
+  for (int i = 0; i < N; ++i) /* :983-992 */
+    gemv_n(y + o->voff[KKT_X_STATE][i], BLK(o, model, KKT_NODE_D2L_DX2, i), o->sd[i], o->sd[i],
+           x + o->voff[KKT_X_STATE][i], 1.0);
+  for (int e = 0; e < E; ++e) { /* :994-1017 */
+    const int parent = o->ws.edge_parents[e], n = o->sd[parent], m = o->cd[e];
+    const double *xp = x + o->voff[KKT_X_STATE][parent], *ue = x + o->voff[KKT_X_CONTROL][e];
+    double *yp = y + o->voff[KKT_X_STATE][parent], *yu = y + o->voff[KKT_X_CONTROL][e];
+    gemv_n(yp, BLK(o, model, KKT_EDGE_D2L_DX2, e), n, n, xp, 1.0);
+    gemv_n(yp, BLK(o, model, KKT_EDGE_D2L_DXDU, e), n, m, ue, 1.0);
+    gemv_t(yu, BLK(o, model, KKT_EDGE_D2L_DXDU, e), n, m, xp);
+    gemv_n(yu, BLK(o, model, KKT_EDGE_D2L_DU2, e), m, m, ue, 1.0);
+  }
+  if (p <= 0) /* :1019-1021 */
+    return;
+  const double *theta = x + sx;
+  double *y_theta = y + sx;
+  for (int i = 0; i < N; ++i) { /* :1029-1041 */
+    const int n = o->sd[i];
+    const double *Hxt = TBLK(o, tm, KKT_TH_NODE_DXDTH, i);
+    gemv_n(y + o->voff[KKT_X_STATE][i], Hxt, n, p, theta, 1.0);
+    gemv_t(y_theta, Hxt, n, p, x + o->voff[KKT_X_STATE][i]);
+    gemv_n(y_theta, TBLK(o, tm, KKT_TH_NODE_DTH2, i), p, p, theta, 1.0);
+  }
+  for (int e = 0; e < E; ++e) { /* :1042-1066 */
+    const int parent = o->ws.edge_parents[e], n = o->sd[parent], m = o->cd[e];
+    const double *Hxt = TBLK(o, tm, KKT_TH_EDGE_DXDTH, e), *Hut = TBLK(o, tm, KKT_TH_EDGE_DUDTH, e);
+    gemv_n(y + o->voff[KKT_X_STATE][parent], Hxt, n, p, theta, 1.0);
+    gemv_n(y + o->voff[KKT_X_CONTROL][e], Hut, m, p, theta, 1.0);
+    gemv_t(y_theta, Hxt, n, p, x + o->voff[KKT_X_STATE][parent]);
+    gemv_t(y_theta, Hut, m, p, x + o->voff[KKT_X_CONTROL][e]);
+    gemv_n(y_theta, TBLK(o, tm, KKT_TH_EDGE_DTH2, e), p, p, theta, 1.0);
+  }
+}
+
+/* CallbackProvider::add_Cx_to_y, helpers.cpp:1069-1159: x in x-space, y in y-space. */
+void kkt_oracle_add_Cx_to_y(const kkt_oracle *o, const double *model, const double *tm,
+                            const double *x, double *y) {
+  const int E = o->E, N = o->N, p = o->p, sx = o->x_dim;
+  const int root = o->ws.preorder_nodes[0];
+  for (int d = 0; d < o->sd[root]; ++d) /* :1074-1081 */
+    y[o->voff[KKT_Y_DYN][root] + d] -= x[o->voff[KKT_X_STATE][root] + d];
+  for (int i = 0; i < N; ++i) /* :1083-1093 */
+    gemv_n(y + o->voff[KKT_Y_NODE_C][i], BLK(o, model, KKT_NODE_DC_DX, i), o->ncd[i], o->sd[i],
+           x + o->voff[KKT_X_STATE][i], 1.0);
+  for (int e = 0; e < E; ++e) { /* :1095-1126 */
+    const int parent = o->ws.edge_parents[e], child = o->ws.edge_children[e];
+    const int np = o->sd[parent], nc = o->sd[child], m = o->cd[e], c = o->ecd[e];
+    const double *xp = x + o->voff[KKT_X_STATE][parent], *ue = x + o->voff[KKT_X_CONTROL][e];
+    double *yd = y + o->voff[KKT_Y_DYN][child], *yc = y + o->voff[KKT_Y_EDGE_C][e];
+    gemv_n(yd, BLK(o, model, KKT_EDGE_DDYN_DX, e), nc, np, xp, 1.0);
+    gemv_n(yd, BLK(o, model, KKT_EDGE_DDYN_DU, e), nc, m, ue, 1.0);
+    for (int d = 0; d < nc; ++d)
+      yd[d] -= x[o->voff[KKT_X_STATE][child] + d];
+    gemv_n(yc, BLK(o, model, KKT_EDGE_DC_DX, e), c, np, xp, 1.0);
+    gemv_n(yc, BLK(o, model, KKT_EDGE_DC_DU, e), c, m, ue, 1.0);
+  }
+  if (p <= 0)
+    return;
+  const double *theta = x + sx;
+  for (int i = 0; i < N; ++i) /* :1135-1143 */
+    gemv_n(y + o->voff[KKT_Y_NODE_C][i], TBLK(o, tm, KKT_TH_NODE_DC, i), o->ncd[i], p, theta, 1.0);
+  for (int e = 0; e < E; ++e) { /* :1144-1158 */
+    const int child = o->ws.edge_children[e];
+    gemv_n(y + o->voff[KKT_Y_DYN][child], TBLK(o, tm, KKT_TH_EDGE_DDYN, e), o->sd[child], p, theta, 1.0);
+    gemv_n(y + o->voff[KKT_Y_EDGE_C][e], TBLK(o, tm, KKT_TH_EDGE_DC, e), o->ecd[e], p, theta, 1.0);
+  }
+}
+
+/* CallbackProvider::add_CTx_to_y, helpers.cpp:1161-1250: x in y-space, y in x-space. */
+void kkt_oracle_add_CTx_to_y(const kkt_oracle *o, const double *model, const double *tm,
+                             const double *x, double *y) {
+  const int E = o->E, N = o->N, p = o->p, sx = o->x_dim;
+  const int root = o->ws.preorder_nodes[0];
+  for (int d = 0; d < o->sd[root]; ++d) /* :1166-1173 */
+    y[o->voff[KKT_X_STATE][root] + d] -= x[o->voff[KKT_Y_DYN][root] + d];
+  for (int i = 0; i < N; ++i) /* :1175-1185 */
+    gemv_t(y + o->voff[KKT_X_STATE][i], BLK(o, model, KKT_NODE_DC_DX, i), o->ncd[i], o->sd[i],
+           x + o->voff[KKT_Y_NODE_C][i]);
+  for (int e = 0; e < E; ++e) { /* :1187-1219 */
+    const int parent = o->ws.edge_parents[e], child = o->ws.edge_children[e];
+    const int np = o->sd[parent], nc = o->sd[child], m = o->cd[e], c = o->ecd[e];
+    const double *dyn = x + o->voff[KKT_Y_DYN][child], *cv = x + o->voff[KKT_Y_EDGE_C][e];
+    double *yp = y + o->voff[KKT_X_STATE][parent], *ych = y + o->voff[KKT_X_STATE][child];
+    double *yu = y + o->voff[KKT_X_CONTROL][e];
+    gemv_t(yp, BLK(o, model, KKT_EDGE_DDYN_DX, e), nc, np, dyn);
+    gemv_t(yp, BLK(o, model, KKT_EDGE_DC_DX, e), c, np, cv);
+    for (int d = 0; d < nc; ++d)
+      ych[d] -= dyn[d];
+    gemv_t(yu, BLK(o, model, KKT_EDGE_DDYN_DU, e), nc, m, dyn);
+    gemv_t(yu, BLK(o, model, KKT_EDGE_DC_DU, e), c, m, cv);
+  }
+  if (p <= 0)
+    return;
+  double *y_theta = y + sx;
+  for (int i = 0; i < N; ++i) /* :1228-1236 */
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_NODE_DC, i), o->ncd[i], p, x + o->voff[KKT_Y_NODE_C][i]);
+  for (int e = 0; e < E; ++e) { /* :1237-1249 */
+    const int child = o->ws.edge_children[e];
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_EDGE_DDYN, e), o->sd[child], p, x + o->voff[KKT_Y_DYN][child]);
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_EDGE_DC, e), o->ecd[e], p, x + o->voff[KKT_Y_EDGE_C][e]);
+  }
+}
+
+/* CallbackProvider::add_Gx_to_y, helpers.cpp:1252-1309: x in x-space, y in z-space. */
+void kkt_oracle_add_Gx_to_y(const kkt_oracle *o, const double *model, const double *tm,
+                            const double *x, double *y) {
+  const int E = o->E, N = o->N, p = o->p, sx = o->x_dim;
+  for (int i = 0; i < N; ++i) /* :1257-1267 */
+    gemv_n(y + o->voff[KKT_Z_NODE][i], BLK(o, model, KKT_NODE_DG_DX, i), o->ngd[i], o->sd[i],
+           x + o->voff[KKT_X_STATE][i], 1.0);
+  for (int e = 0; e < E; ++e) { /* :1268-1283 */
+    const int parent = o->ws.edge_parents[e], n = o->sd[parent], m = o->cd[e], g = o->egd[e];
+    gemv_n(y + o->voff[KKT_Z_EDGE][e], BLK(o, model, KKT_EDGE_DG_DX, e), g, n, x + o->voff[KKT_X_STATE][parent], 1.0);
+    gemv_n(y + o->voff[KKT_Z_EDGE][e], BLK(o, model, KKT_EDGE_DG_DU, e), g, m, x + o->voff[KKT_X_CONTROL][e], 1.0);
+  }
+  if (p <= 0)
+    return;
+  const double *theta = x + sx;
+  for (int i = 0; i < N; ++i) /* :1292-1299 */
+    gemv_n(y + o->voff[KKT_Z_NODE][i], TBLK(o, tm, KKT_TH_NODE_DG, i), o->ngd[i], p, theta, 1.0);
+  for (int e = 0; e < E; ++e) /* :1300-1308 */
+    gemv_n(y + o->voff[KKT_Z_EDGE][e], TBLK(o, tm, KKT_TH_EDGE_DG, e), o->egd[e], p, theta, 1.0);
+}
+
+/* CallbackProvider::add_GTx_to_y, helpers.cpp:1311-1368: x in z-space, y in x-space. */
+void kkt_oracle_add_GTx_to_y(const kkt_oracle *o, const double *model, const double *tm,
+                             const double *x, double *y) {
+  const int E = o->E, N = o->N, p = o->p, sx = o->x_dim;
+  for (int i = 0; i < N; ++i) /* :1316-1326 */
+    gemv_t(y + o->voff[KKT_X_STATE][i], BLK(o, model, KKT_NODE_DG_DX, i), o->ngd[i], o->sd[i],
+           x + o->voff[KKT_Z_NODE][i]);
+  for (int e = 0; e < E; ++e) { /* :1327-1342 */
+    const int parent = o->ws.edge_parents[e], n = o->sd[parent], m = o->cd[e], g = o->egd[e];
+    gemv_t(y + o->voff[KKT_X_STATE][parent], BLK(o, model, KKT_EDGE_DG_DX, e), g, n, x + o->voff[KKT_Z_EDGE][e]);
+    gemv_t(y + o->voff[KKT_X_CONTROL][e], BLK(o, model, KKT_EDGE_DG_DU, e), g, m, x + o->voff[KKT_Z_EDGE][e]);
+  }
+  if (p <= 0)
+    return;
+  double *y_theta = y + sx;
+  for (int i = 0; i < N; ++i) /* :1351-1358 */
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_NODE_DG, i), o->ngd[i], p, x + o->voff[KKT_Z_NODE][i]);
+  for (int e = 0; e < E; ++e) /* :1359-1367 */
+    gemv_t(y_theta, TBLK(o, tm, KKT_TH_EDGE_DG, e), o->egd[e], p, x + o->voff[KKT_Z_EDGE][e]);
+}

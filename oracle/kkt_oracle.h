@@ -131,6 +131,23 @@ void kkt_oracle_add_Kx_to_y_theta(const kkt_oracle *o, const double *model, cons
                                   const double *w, const double *r1, const double *r2, const double *r3,
                                   const double *x, double *y);
 
+/* The five block operators of CallbackProvider (helpers.hpp:20-24, bodies helpers.cpp:978-1368),
+ * y += (block) x, each restated from its own body.  Vector spaces: x-space = [stagewise x | theta
+ * (p entries, when kkt_oracle_set_theta was called)], y-space = y_dim, z-space = z_dim entries.
+ *   Hx : x-space -> x-space    Cx : x-space -> y-space    CTx : y-space -> x-space
+ *   Gx : x-space -> z-space    GTx: z-space -> x-space
+ * theta_model: the theta arena, ignored (may be NULL) while theta_dim == 0. */
+void kkt_oracle_add_Hx_to_y(const kkt_oracle *o, const double *model, const double *theta_model,
+                            const double *x, double *y);
+void kkt_oracle_add_Cx_to_y(const kkt_oracle *o, const double *model, const double *theta_model,
+                            const double *x, double *y);
+void kkt_oracle_add_CTx_to_y(const kkt_oracle *o, const double *model, const double *theta_model,
+                             const double *x, double *y);
+void kkt_oracle_add_Gx_to_y(const kkt_oracle *o, const double *model, const double *theta_model,
+                            const double *x, double *y);
+void kkt_oracle_add_GTx_to_y(const kkt_oracle *o, const double *model, const double *theta_model,
+                             const double *x, double *y);
+
 /* factor + solve of `batch` problems sharing the topology (arenas strided by
  * the per-problem lengths), OpenMP over problems with one handle per thread.
  * status[p] as kkt_oracle_factor. */

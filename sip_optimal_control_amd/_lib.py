@@ -78,6 +78,9 @@ _SIGNATURES = {
     "sip_kkt_solve_theta": (ctypes.c_int, [_P] * 9),
     "sip_kkt_add_Kx_to_y_theta": (ctypes.c_int, [_P] * 10),
 }
+for _op in ("Hx", "Cx", "CTx", "Gx", "GTx"):  # the five block operators, helpers.hpp:20-24
+    _SIGNATURES[f"sip_kkt_add_{_op}_to_y"] = (ctypes.c_int, [_P] * 5)
+    _SIGNATURES[f"sip_kkt_add_{_op}_to_y_theta"] = (ctypes.c_int, [_P] * 6)
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

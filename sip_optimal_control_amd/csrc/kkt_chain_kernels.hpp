@@ -573,15 +573,16 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
   }
 }
 
-// y += K x (helpers.cpp:953-1368) for a uniform chain.  The workgroup of stage i owns the state
-// and control rows of stage i, the dynamics rows of node i + 1 (plus the root's at i = 0) and the
-// constraint rows of node i and edge i: everything they touch is in stage i's model item (staged
-// in LDS) and in a few slices of x.  Vectors are [x | theta (th entries) | y | z].
+// y += K x (helpers.cpp:953-1368), or the selected blocks of it (ApplyIO::parts: the five operators
+// of helpers.hpp:20-24), for a uniform chain.  The workgroup of stage i owns the state and control
+// rows of stage i, the dynamics rows of node i + 1 (plus the root's at i = 0) and the constraint
+// rows of node i and edge i: everything they touch is in stage i's model item (staged in LDS) and
+// in a few slices of x.  x-space vectors are [x | theta (th entries)].
 __global__ void __launch_bounds__(TPB)
 apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ model_all,
                    const double *__restrict__ w_all, const double *__restrict__ r1_all,
-                   const double *__restrict__ r2_all, const double *__restrict__ r3_all,
-                   const double *__restrict__ x_all, double *__restrict__ y_all, long batch) {
+                   const double *__restrict__ r2_all, const double *__restrict__ r3_all, const ApplyIO io,
+                   long batch) {
   extern __shared__ double sm[];
   const int n = ck.n, m = ck.m, T = ck.T;
   const long p = blockIdx.x / (T + 1);
@@ -589,70 +590,83 @@ apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ m
   if (p >= batch)
     return;
   const int tid = threadIdx.x;
+  const int parts = io.parts;
+  const bool pH = parts & AP_H, pC = parts & AP_C, pCT = parts & AP_CT, pG = parts & AP_G, pGT = parts & AP_GT,
+             pR = parts & AP_REG;
+  const bool out_x = pH || pCT || pGT || pR, out_y = pC || pR, out_z = pG || pR;
   const bool last = i == T;
   const int c = last ? ck.cT : ck.cn, g = last ? ck.gT : ck.gn;
   const int ce = last ? 0 : ck.ce, ge = last ? 0 : ck.ge;
   const int nn = n * n, nm = n * m;
   const int node_len = nn + (c + g) * n, edge_len = last ? 0 : ck.edge_len;
   const int xt = ck.x_dim + th;
-  const long full = (long)xt + ck.y_dim + ck.z_dim;
   const double *item = model_all + p * ck.model_len + (long)i * (ck.node_len + ck.edge_len);
   const int x_s = i * (n + m), x_u = x_s + n;
   const int y_dyn = i * (n + ck.cn), y_nc = y_dyn + n, y_next = y_dyn + n + ck.cn;
   const int y_ec = T * (n + ck.cn) + n + ck.cT + i * ck.ce;
   const int z_n = i * ck.gn, z_e = T * ck.gn + ck.gT + i * ck.ge;
   const double *w = w_all + p * ck.z_dim, *r1 = r1_all + p * xt, *r2 = r2_all + p * ck.y_dim;
-  const double *r3 = r3_all + p * ck.z_dim;
-  const double *x_x = x_all + p * full, *x_y = x_x + xt, *x_z = x_y + ck.y_dim;
-  double *y_x = y_all + p * full, *y_y = y_x + xt, *y_z = y_y + ck.y_dim;
+  const double *r3 = r3_all + p * ck.z_dim; // dereferenced under AP_REG only
+  const bool in_x = io.x_x != nullptr, in_y = io.x_y != nullptr, in_z = io.x_z != nullptr;
+  const double *x_x = io.x_x + p * io.sx, *x_y = io.x_y + p * io.sy, *x_z = io.x_z + p * io.sz;
+  double *y_x = io.y_x + p * io.sx, *y_y = io.y_y + p * io.sy, *y_z = io.y_z + p * io.sz;
 
   double *buf = sm, *v = buf + ck.lds_item;
   // vector slices in LDS: x_i | u_i | ydyn_i | ydyn_{i+1} | yc_node | z_node | yc_edge | z_edge
   double *vx = v, *vu = vx + n, *vd = vu + m, *vdn = vd + n, *vyc = vdn + n, *vzn = vyc + c, *vye = vzn + g,
          *vze = vye + ce;
-  // Output row r of the stage: where it lives in y, its regularization coefficient
-  // (r1 | r2 | w + r3) and, for a dynamics row of node i + 1, the -x_{i+1} entry.
+  // Output row r of the stage: where it lives in y (null: its space is not an output of this
+  // launch), its regularization coefficient (r1 | r2 | w + r3) and, for a dynamics row of node
+  // i + 1, the -x_{i+1} entry.
   const int n_rows = n + (last ? 0 : m + n) + c + g + ce + ge + (i == 0 ? n : 0);
   auto row_io = [&](int q, double *&dst, double &coef, double &extra) {
-    extra = 0.0;
+    extra = 0.0, coef = 0.0, dst = nullptr;
     if (q < n) {
-      dst = y_x + x_s + q, coef = r1[x_s + q];
+      if (out_x)
+        dst = y_x + x_s + q, coef = pR ? r1[x_s + q] : 0.0;
       return;
     }
     q -= n;
     if (!last) {
       if (q < m) {
-        dst = y_x + x_u + q, coef = r1[x_u + q];
+        if (out_x)
+          dst = y_x + x_u + q, coef = pR ? r1[x_u + q] : 0.0;
         return;
       }
       q -= m;
       if (q < n) {
-        dst = y_y + y_next + q, coef = r2[y_next + q], extra = x_x[x_s + n + m + q];
+        if (out_y)
+          dst = y_y + y_next + q, coef = pR ? r2[y_next + q] : 0.0, extra = pC ? x_x[x_s + n + m + q] : 0.0;
         return;
       }
       q -= n;
     }
     if (q < c) {
-      dst = y_y + y_nc + q, coef = r2[y_nc + q];
+      if (out_y)
+        dst = y_y + y_nc + q, coef = pR ? r2[y_nc + q] : 0.0;
       return;
     }
     q -= c;
     if (q < g) {
-      dst = y_z + z_n + q, coef = w[z_n + q] + r3[z_n + q];
+      if (out_z)
+        dst = y_z + z_n + q, coef = pR ? w[z_n + q] + r3[z_n + q] : 0.0;
       return;
     }
     q -= g;
     if (q < ce) {
-      dst = y_y + y_ec + q, coef = r2[y_ec + q];
+      if (out_y)
+        dst = y_y + y_ec + q, coef = pR ? r2[y_ec + q] : 0.0;
       return;
     }
     q -= ce;
     if (q < ge) {
-      dst = y_z + z_e + q, coef = w[z_e + q] + r3[z_e + q];
+      if (out_z)
+        dst = y_z + z_e + q, coef = pR ? w[z_e + q] + r3[z_e + q] : 0.0;
       return;
     }
     q -= ge;
-    dst = y_y + y_dyn + q, coef = r2[y_dyn + q];
+    if (out_y)
+      dst = y_y + y_dyn + q, coef = pR ? r2[y_dyn + q] : 0.0;
   };
   // Every small read of the wavefront -- the slices of x and the lane's first output row -- is
   // issued ahead of the stage copy: one HBM round trip per wavefront instead of three.
@@ -660,24 +674,28 @@ apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ m
   double coef0 = 0.0, extra0 = 0.0, yold0 = 0.0;
   if (tid < n_rows) {
     row_io(tid, dst0, coef0, extra0);
-    yold0 = *dst0;
+    if (dst0 != nullptr)
+      yold0 = *dst0;
   }
   double px = 0.0, pd = 0.0, pdn = 0.0, pu = 0.0, pyc = 0.0, pzn = 0.0, pye = 0.0, pze = 0.0;
   if (tid < n) {
-    px = x_x[x_s + tid];
-    pd = x_y[y_dyn + tid];
-    if (!last)
-      pdn = x_y[y_next + tid];
+    if (in_x)
+      px = x_x[x_s + tid];
+    if (in_y) {
+      pd = x_y[y_dyn + tid];
+      if (!last)
+        pdn = x_y[y_next + tid];
+    }
   }
-  if (!last && tid < m)
+  if (!last && tid < m && in_x)
     pu = x_x[x_u + tid];
-  if (tid < c)
+  if (tid < c && in_y)
     pyc = x_y[y_nc + tid];
-  if (tid < g)
+  if (tid < g && in_z)
     pzn = x_z[z_n + tid];
-  if (tid < ce)
+  if (tid < ce && in_y)
     pye = x_y[y_ec + tid];
-  if (tid < ge)
+  if (tid < ge && in_z)
     pze = x_z[z_e + tid];
   stage_copy2(buf, item, node_len + edge_len, tid);
   if (tid < n) {
@@ -698,13 +716,13 @@ apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ m
     vze[tid] = pze;
   for (int k = tid + TPB; k < c + g + ce + ge; k += TPB) { // more than 64 rows of one kind
     if (k < c)
-      vyc[k] = x_y[y_nc + k];
+      vyc[k] = in_y ? x_y[y_nc + k] : 0.0;
     if (k < g)
-      vzn[k] = x_z[z_n + k];
+      vzn[k] = in_z ? x_z[z_n + k] : 0.0;
     if (k < ce)
-      vye[k] = x_y[y_ec + k];
+      vye[k] = in_y ? x_y[y_ec + k] : 0.0;
     if (k < ge)
-      vze[k] = x_z[z_e + k];
+      vze[k] = in_z ? x_z[z_e + k] : 0.0;
   }
   __syncthreads();
   const double *Q = buf, *Jc = buf + nn, *Jg = Jc + c * n, *eb = buf + node_len;
@@ -723,59 +741,85 @@ apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ m
       acc += a[r] * vec[r];
     return acc;
   };
+  const bool all = parts == AP_ALL;
   for (int r = tid; r < n_rows; r += TPB) {
     int q = r;
     double *dst = dst0;
     double coef = coef0, extra = extra0, yold = yold0;
     if (r != tid) {
       row_io(r, dst, coef, extra);
-      yold = *dst;
+      if (dst != nullptr)
+        yold = *dst;
     }
+    if (dst == nullptr) // a row of a space this launch does not write
+      continue;
     if (q < n) { // state rows: H x + C^T y + G^T z + r1 x
-      double acc = dotr(Q, n, q, n, vx) + dotc(Jc, c, q, c, vyc) + dotc(Jg, g, q, g, vzn) - vd[q];
-      if (!last)
-        acc += dotr(eQ, n, q, n, vx) + dotr(M, n, q, m, vu) + dotc(A, n, q, n, vdn) + dotc(Jxc, ce, q, ce, vye) +
-               dotc(Jxg, ge, q, ge, vze);
+      double acc;
+      if (all) { // the whole operator, summed in one fixed order
+        acc = dotr(Q, n, q, n, vx) + dotc(Jc, c, q, c, vyc) + dotc(Jg, g, q, g, vzn) - vd[q];
+        if (!last)
+          acc += dotr(eQ, n, q, n, vx) + dotr(M, n, q, m, vu) + dotc(A, n, q, n, vdn) + dotc(Jxc, ce, q, ce, vye) +
+                 dotc(Jxg, ge, q, ge, vze);
+      } else {
+        acc = 0.0;
+        if (pH)
+          acc += dotr(Q, n, q, n, vx) + (last ? 0.0 : dotr(eQ, n, q, n, vx) + dotr(M, n, q, m, vu));
+        if (pCT)
+          acc += dotc(Jc, c, q, c, vyc) - vd[q] + (last ? 0.0 : dotc(A, n, q, n, vdn) + dotc(Jxc, ce, q, ce, vye));
+        if (pGT)
+          acc += dotc(Jg, g, q, g, vzn) + (last ? 0.0 : dotc(Jxg, ge, q, ge, vze));
+      }
       *dst = yold + (acc + coef * vx[q]);
       continue;
     }
     q -= n;
     if (!last) {
       if (q < m) { // control rows
-        const double acc = dotc(M, n, q, n, vx) + dotr(R, m, q, m, vu) + dotc(B, n, q, n, vdn) +
-                           dotc(Juc, ce, q, ce, vye) + dotc(Jug, ge, q, ge, vze);
+        double acc;
+        if (all) {
+          acc = dotc(M, n, q, n, vx) + dotr(R, m, q, m, vu) + dotc(B, n, q, n, vdn) + dotc(Juc, ce, q, ce, vye) +
+                dotc(Jug, ge, q, ge, vze);
+        } else {
+          acc = 0.0;
+          if (pH)
+            acc += dotc(M, n, q, n, vx) + dotr(R, m, q, m, vu);
+          if (pCT)
+            acc += dotc(B, n, q, n, vdn) + dotc(Juc, ce, q, ce, vye);
+          if (pGT)
+            acc += dotc(Jug, ge, q, ge, vze);
+        }
         *dst = yold + (acc + coef * vu[q]);
         continue;
       }
       q -= m;
       if (q < n) { // dynamics rows of node i + 1: A x + B u - x_{i+1} - r2 y
-        const double acc = dotr(A, n, q, n, vx) + dotr(B, n, q, m, vu) - extra;
+        const double acc = pC ? dotr(A, n, q, n, vx) + dotr(B, n, q, m, vu) - extra : 0.0;
         *dst = yold + (acc - coef * vdn[q]);
         continue;
       }
       q -= n;
     }
     if (q < c) {
-      *dst = yold + (dotr(Jc, c, q, n, vx) - coef * vyc[q]);
+      *dst = yold + ((pC ? dotr(Jc, c, q, n, vx) : 0.0) - coef * vyc[q]);
       continue;
     }
     q -= c;
     if (q < g) {
-      *dst = yold + (dotr(Jg, g, q, n, vx) - coef * vzn[q]);
+      *dst = yold + ((pG ? dotr(Jg, g, q, n, vx) : 0.0) - coef * vzn[q]);
       continue;
     }
     q -= g;
     if (q < ce) {
-      *dst = yold + (dotr(Jxc, ce, q, n, vx) + dotr(Juc, ce, q, m, vu) - coef * vye[q]);
+      *dst = yold + ((pC ? dotr(Jxc, ce, q, n, vx) + dotr(Juc, ce, q, m, vu) : 0.0) - coef * vye[q]);
       continue;
     }
     q -= ce;
     if (q < ge) {
-      *dst = yold + (dotr(Jxg, ge, q, n, vx) + dotr(Jug, ge, q, m, vu) - coef * vze[q]);
+      *dst = yold + ((pG ? dotr(Jxg, ge, q, n, vx) + dotr(Jug, ge, q, m, vu) : 0.0) - coef * vze[q]);
       continue;
     }
     q -= ge; // i == 0: the root's dynamics rows, -x_root - r2 y (helpers.cpp:1081-1085)
-    *dst = yold + (-vx[q] - coef * vd[q]);
+    *dst = yold + ((pC ? -vx[q] : 0.0) - coef * vd[q]);
   }
 }
 

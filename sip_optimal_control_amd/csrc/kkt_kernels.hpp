@@ -597,89 +597,146 @@ __device__ __forceinline__ double col_dot(const double *J, int col, int rows, co
   return acc;
 }
 
-// y += K x, gather form: the lanes of a node item own the node's state rows of
-// y_x, its dynamics rows and node constraint rows of y_y, and its rows of y_z;
-// the lanes of an edge item own the control rows and the edge constraint rows.
+// Which blocks of K = [[H + r1, C^T, G^T], [C, -r2, 0], [G, 0, -(w + r3)]] an apply launch adds:
+// CallbackProvider::add_Kx_to_y (helpers.cpp:953-976) is all of them, the five operators SIP is
+// handed one by one (helpers.hpp:20-24; sip_optimal_control.cpp:147-190) are one bit each.
+enum ApplyPart { AP_H = 1, AP_C = 2, AP_CT = 4, AP_G = 8, AP_GT = 16, AP_REG = 32, AP_ALL = 63 };
+
+// Input / output vectors of an apply launch by vector space: x-space = [stagewise x | theta],
+// y-space, z-space; a space no selected block reads (writes) may be null.  Strides are per problem,
+// in doubles: one KKT vector [x | theta | y | z] has all three equal to its length.
+struct ApplyIO {
+  const double *x_x, *x_y, *x_z;
+  double *y_x, *y_y, *y_z;
+  long sx, sy, sz;
+  int parts;
+};
+
+// y += K x (or the selected blocks of it), gather form: the lanes of a node item own the node's
+// state rows of y_x, its dynamics rows and node constraint rows of y_y, and its rows of y_z; the
+// lanes of an edge item own the control rows and the edge constraint rows.
 __global__ void __launch_bounds__(TPB)
 apply_kernel(const Meta mt, const double *__restrict__ model_all, const double *__restrict__ w_all,
              const double *__restrict__ r1_all, const double *__restrict__ r2_all,
-             const double *__restrict__ r3_all, const double *__restrict__ x_all, double *__restrict__ y_all,
-             long batch) {
+             const double *__restrict__ r3_all, const ApplyIO io, long batch) {
   const int items = mt.N + mt.E;
   const long p = blockIdx.x / items;
   const int item = blockIdx.x - (unsigned)(p * items);
   if (p >= batch)
     return;
-  const int xt = mt.x_dim + mt.theta_dim; // theta (if any) sits between x and y
-  const long kkt = (long)xt + mt.y_dim + mt.z_dim;
+  const int parts = io.parts;
+  const bool pH = parts & AP_H, pC = parts & AP_C, pCT = parts & AP_CT, pG = parts & AP_G, pGT = parts & AP_GT,
+             pR = parts & AP_REG;
+  const bool out_x = pH || pCT || pGT || pR, out_y = pC || pR, out_z = pG || pR;
+  const int xt = mt.x_dim + mt.theta_dim; // theta (if any) sits behind the stagewise x
   const double *model = model_all + p * mt.model_len;
-  const double *w = w_all + p * mt.z_dim, *r1 = r1_all + p * xt, *r2 = r2_all + p * mt.y_dim;
-  const double *r3 = r3_all + p * mt.z_dim;
-  const double *x_x = x_all + p * kkt, *x_y = x_x + xt, *x_z = x_y + mt.y_dim;
-  double *y_x = y_all + p * kkt, *y_y = y_x + xt, *y_z = y_y + mt.y_dim;
+  // regularization diagonal (AP_REG only; null otherwise)
+  const double *w = pR ? w_all + p * mt.z_dim : nullptr, *r1 = pR ? r1_all + p * xt : nullptr;
+  const double *r2 = pR ? r2_all + p * mt.y_dim : nullptr, *r3 = pR ? r3_all + p * mt.z_dim : nullptr;
+  const double *x_x = io.x_x ? io.x_x + p * io.sx : nullptr, *x_y = io.x_y ? io.x_y + p * io.sy : nullptr;
+  const double *x_z = io.x_z ? io.x_z + p * io.sz : nullptr;
+  double *y_x = io.y_x ? io.y_x + p * io.sx : nullptr, *y_y = io.y_y ? io.y_y + p * io.sy : nullptr;
+  double *y_z = io.y_z ? io.y_z + p * io.sz : nullptr;
   const int tid = threadIdx.x;
   if (item < mt.N) {
     const int i = item, n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];
-    const double *xs = x_x + mt.x_state[i];
+    const double *xs = x_x ? x_x + mt.x_state[i] : nullptr;
     const int lo = mt.child_offsets[i], hi = mt.child_offsets[i + 1];
     const int ine = mt.in_edge[i]; // -1 at the root
     for (int r = tid; r < 2 * n + c + g; r += TPB) {
       if (r < n) { // state rows of y_x: H x + C^T y + G^T z + r1 x
+        if (!out_x)
+          continue;
         const int d = r;
-        double acc = row_dot(model + mt.mo[N_Q][i], d, n, n, xs);
-        acc += col_dot(model + mt.mo[N_JC][i], d, c, x_y + mt.y_node_c[i]);
-        acc += col_dot(model + mt.mo[N_JG][i], d, g, x_z + mt.z_node[i]);
-        acc -= x_y[mt.y_dyn[i] + d]; // -I of the node's own dynamics / initial-state row
+        double acc = 0.0;
+        if (pH)
+          acc = row_dot(model + mt.mo[N_Q][i], d, n, n, xs);
+        if (pCT)
+          acc += col_dot(model + mt.mo[N_JC][i], d, c, x_y + mt.y_node_c[i]);
+        if (pGT)
+          acc += col_dot(model + mt.mo[N_JG][i], d, g, x_z + mt.z_node[i]);
+        if (pCT)
+          acc -= x_y[mt.y_dyn[i] + d]; // -I of the node's own dynamics / initial-state row
         for (int ci = lo; ci < hi; ++ci) {
           const int e = mt.child_edges[ci], ch = mt.child[e], m = mt.cd[e];
-          acc += row_dot(model + mt.mo[E_Q][e], d, n, n, xs);
-          acc += row_dot(model + mt.mo[E_M][e], d, n, m, x_x + mt.x_control[e]);
-          acc += col_dot(model + mt.mo[E_A][e], d, mt.sd[ch], x_y + mt.y_dyn[ch]);
-          acc += col_dot(model + mt.mo[E_JXC][e], d, mt.ecd[e], x_y + mt.y_edge_c[e]);
-          acc += col_dot(model + mt.mo[E_JXG][e], d, mt.egd[e], x_z + mt.z_edge[e]);
+          if (pH) {
+            acc += row_dot(model + mt.mo[E_Q][e], d, n, n, xs);
+            acc += row_dot(model + mt.mo[E_M][e], d, n, m, x_x + mt.x_control[e]);
+          }
+          if (pCT) {
+            acc += col_dot(model + mt.mo[E_A][e], d, mt.sd[ch], x_y + mt.y_dyn[ch]);
+            acc += col_dot(model + mt.mo[E_JXC][e], d, mt.ecd[e], x_y + mt.y_edge_c[e]);
+          }
+          if (pGT)
+            acc += col_dot(model + mt.mo[E_JXG][e], d, mt.egd[e], x_z + mt.z_edge[e]);
         }
         const int at = mt.x_state[i] + d;
-        y_x[at] += acc + r1[at] * x_x[at];
+        y_x[at] += pR ? acc + r1[at] * x_x[at] : acc;
       } else if (r < 2 * n) { // dynamics rows of y_y
+        if (!out_y)
+          continue;
         const int d = r - n;
-        double acc = -xs[d];
-        if (ine >= 0) {
-          const int e = ine, pa = mt.parent[e];
-          acc += row_dot(model + mt.mo[E_A][e], d, n, mt.sd[pa], x_x + mt.x_state[pa]);
-          acc += row_dot(model + mt.mo[E_B][e], d, n, mt.cd[e], x_x + mt.x_control[e]);
+        double acc = 0.0;
+        if (pC) {
+          acc = -xs[d];
+          if (ine >= 0) {
+            const int e = ine, pa = mt.parent[e];
+            acc += row_dot(model + mt.mo[E_A][e], d, n, mt.sd[pa], x_x + mt.x_state[pa]);
+            acc += row_dot(model + mt.mo[E_B][e], d, n, mt.cd[e], x_x + mt.x_control[e]);
+          }
         }
         const int at = mt.y_dyn[i] + d;
-        y_y[at] += acc - r2[at] * x_y[at];
+        y_y[at] += pR ? acc - r2[at] * x_y[at] : acc;
       } else if (r < 2 * n + c) {
+        if (!out_y)
+          continue;
         const int k = r - 2 * n, at = mt.y_node_c[i] + k;
-        y_y[at] += row_dot(model + mt.mo[N_JC][i], k, c, n, xs) - r2[at] * x_y[at];
+        const double acc = pC ? row_dot(model + mt.mo[N_JC][i], k, c, n, xs) : 0.0;
+        y_y[at] += pR ? acc - r2[at] * x_y[at] : acc;
       } else {
+        if (!out_z)
+          continue;
         const int k = r - 2 * n - c, at = mt.z_node[i] + k;
-        y_z[at] += row_dot(model + mt.mo[N_JG][i], k, g, n, xs) - (w[at] + r3[at]) * x_z[at];
+        const double acc = pG ? row_dot(model + mt.mo[N_JG][i], k, g, n, xs) : 0.0;
+        y_z[at] += pR ? acc - (w[at] + r3[at]) * x_z[at] : acc;
       }
     }
   } else {
     const int e = item - mt.N, pa = mt.parent[e], ch = mt.child[e];
     const int n = mt.sd[pa], nc = mt.sd[ch], m = mt.cd[e], c = mt.ecd[e], g = mt.egd[e];
-    const double *xp = x_x + mt.x_state[pa], *ue = x_x + mt.x_control[e];
+    const double *xp = x_x ? x_x + mt.x_state[pa] : nullptr, *ue = x_x ? x_x + mt.x_control[e] : nullptr;
     for (int r = tid; r < m + c + g; r += TPB) {
       if (r < m) { // control rows of y_x
+        if (!out_x)
+          continue;
         const int d = r;
-        double acc = col_dot(model + mt.mo[E_M][e], d, n, xp);
-        acc += row_dot(model + mt.mo[E_R][e], d, m, m, ue);
-        acc += col_dot(model + mt.mo[E_B][e], d, nc, x_y + mt.y_dyn[ch]);
-        acc += col_dot(model + mt.mo[E_JUC][e], d, c, x_y + mt.y_edge_c[e]);
-        acc += col_dot(model + mt.mo[E_JUG][e], d, g, x_z + mt.z_edge[e]);
+        double acc = 0.0;
+        if (pH) {
+          acc = col_dot(model + mt.mo[E_M][e], d, n, xp);
+          acc += row_dot(model + mt.mo[E_R][e], d, m, m, ue);
+        }
+        if (pCT) {
+          acc += col_dot(model + mt.mo[E_B][e], d, nc, x_y + mt.y_dyn[ch]);
+          acc += col_dot(model + mt.mo[E_JUC][e], d, c, x_y + mt.y_edge_c[e]);
+        }
+        if (pGT)
+          acc += col_dot(model + mt.mo[E_JUG][e], d, g, x_z + mt.z_edge[e]);
         const int at = mt.x_control[e] + d;
-        y_x[at] += acc + r1[at] * x_x[at];
+        y_x[at] += pR ? acc + r1[at] * x_x[at] : acc;
       } else if (r < m + c) {
+        if (!out_y)
+          continue;
         const int k = r - m, at = mt.y_edge_c[e] + k;
-        const double acc = row_dot(model + mt.mo[E_JXC][e], k, c, n, xp) + row_dot(model + mt.mo[E_JUC][e], k, c, m, ue);
-        y_y[at] += acc - r2[at] * x_y[at];
+        const double acc =
+            pC ? row_dot(model + mt.mo[E_JXC][e], k, c, n, xp) + row_dot(model + mt.mo[E_JUC][e], k, c, m, ue) : 0.0;
+        y_y[at] += pR ? acc - r2[at] * x_y[at] : acc;
       } else {
+        if (!out_z)
+          continue;
         const int k = r - m - c, at = mt.z_edge[e] + k;
-        const double acc = row_dot(model + mt.mo[E_JXG][e], k, g, n, xp) + row_dot(model + mt.mo[E_JUG][e], k, g, m, ue);
-        y_z[at] += acc - (w[at] + r3[at]) * x_z[at];
+        const double acc =
+            pG ? row_dot(model + mt.mo[E_JXG][e], k, g, n, xp) + row_dot(model + mt.mo[E_JUG][e], k, g, m, ue) : 0.0;
+        y_z[at] += pR ? acc - (w[at] + r3[at]) * x_z[at] : acc;
       }
     }
   }

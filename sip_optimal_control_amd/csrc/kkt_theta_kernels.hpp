@@ -283,20 +283,27 @@ theta_finish_kernel(const Meta mt, const ThetaMeta th, const double *__restrict_
     sol[sx + a] = sm[a];
 }
 
-// Theta terms of y += K x on vectors [x | theta | y | z].  One workgroup per problem; lane a < p
+// Theta terms of y += K x (or of the selected blocks of it, ApplyIO::parts: the theta sections of
+// add_Hx / Cx / CTx / Gx / GTx_to_y, helpers.cpp:1023-1066, 1128-1158, 1221-1249, 1285-1308,
+// 1344-1367).  x-space vectors are [stagewise x | theta].  One workgroup per problem; lane a < p
 // accumulates y_theta[a]; the rows coupled to theta are updated by the lanes in turn.
 __global__ void __launch_bounds__(TPB)
 apply_theta_kernel(const Meta mt, const ThetaMeta th, const double *__restrict__ theta_all,
-                   const double *__restrict__ r1_all, const double *__restrict__ x_all,
-                   double *__restrict__ y_all, long batch) {
+                   const double *__restrict__ r1_all, const ApplyIO io, long batch) {
   const long prob = blockIdx.x;
   if (prob >= batch)
     return;
-  const int tid = threadIdx.x, p = th.p, sx = mt.x_dim, yd = mt.y_dim;
-  const long full = (long)sx + p + yd + mt.z_dim;
+  const int tid = threadIdx.x, p = th.p, sx = mt.x_dim;
+  const int parts = io.parts;
+  const bool pH = parts & AP_H, pC = parts & AP_C, pCT = parts & AP_CT, pG = parts & AP_G, pGT = parts & AP_GT,
+             pR = parts & AP_REG;
   const double *tm = theta_all + prob * th.theta_len;
-  const double *x_x = x_all + prob * full, *theta = x_x + sx, *x_y = theta + p, *x_z = x_y + yd;
-  double *y_x = y_all + prob * full, *y_theta = y_x + sx, *y_y = y_theta + p, *y_z = y_y + yd;
+  const double *x_x = io.x_x ? io.x_x + prob * io.sx : nullptr, *x_y = io.x_y ? io.x_y + prob * io.sy : nullptr;
+  const double *x_z = io.x_z ? io.x_z + prob * io.sz : nullptr;
+  double *y_x = io.y_x ? io.y_x + prob * io.sx : nullptr, *y_y = io.y_y ? io.y_y + prob * io.sy : nullptr;
+  double *y_z = io.y_z ? io.y_z + prob * io.sz : nullptr;
+  const double *theta = x_x ? x_x + sx : nullptr; // read by H, C, G (and the r1 term)
+  double *y_theta = y_x ? y_x + sx : nullptr;     // written by H, CT, GT (and the r1 term)
   // rows += M theta (M rows x p); lanes over rows
   auto add_M_theta = [&](double *dst, const double *M, int rows) {
     for (int r = tid; r < rows; r += TPB) {
@@ -327,33 +334,47 @@ apply_theta_kernel(const Meta mt, const ThetaMeta th, const double *__restrict__
   for (int i = 0; i < mt.N; ++i) {
     const int n = mt.sd[i], c = mt.ncd[i], g = mt.ngd[i];
     const double *Hxt = tm + th.to[TH_N_X][i];
-    add_M_theta(y_x + mt.x_state[i], Hxt, n);
-    add_MT_v(Hxt, n, x_x + mt.x_state[i]);
-    add_M_own(tm + th.to[TH_N_TT][i]); // y_theta += H_theta_theta theta (:1038-1040)
-    add_M_theta(y_y + mt.y_node_c[i], tm + th.to[TH_N_C][i], c);
-    add_MT_v(tm + th.to[TH_N_C][i], c, x_y + mt.y_node_c[i]);
-    add_M_theta(y_z + mt.z_node[i], tm + th.to[TH_N_G][i], g);
-    add_MT_v(tm + th.to[TH_N_G][i], g, x_z + mt.z_node[i]);
+    if (pH) {
+      add_M_theta(y_x + mt.x_state[i], Hxt, n);
+      add_MT_v(Hxt, n, x_x + mt.x_state[i]);
+      add_M_own(tm + th.to[TH_N_TT][i]); // y_theta += H_theta_theta theta (:1038-1040)
+    }
+    if (pC)
+      add_M_theta(y_y + mt.y_node_c[i], tm + th.to[TH_N_C][i], c);
+    if (pCT)
+      add_MT_v(tm + th.to[TH_N_C][i], c, x_y + mt.y_node_c[i]);
+    if (pG)
+      add_M_theta(y_z + mt.z_node[i], tm + th.to[TH_N_G][i], g);
+    if (pGT)
+      add_MT_v(tm + th.to[TH_N_G][i], g, x_z + mt.z_node[i]);
     __syncthreads(); // edge terms below add to the same state rows
   }
   for (int e = 0; e < mt.E; ++e) {
     const int pa = mt.parent[e], ch = mt.child[e];
     const int n = mt.sd[pa], nc = mt.sd[ch], m = mt.cd[e], c = mt.ecd[e], g = mt.egd[e];
-    add_M_theta(y_x + mt.x_state[pa], tm + th.to[TH_E_X][e], n);
-    add_M_theta(y_x + mt.x_control[e], tm + th.to[TH_E_U][e], m);
-    add_MT_v(tm + th.to[TH_E_X][e], n, x_x + mt.x_state[pa]);
-    add_MT_v(tm + th.to[TH_E_U][e], m, x_x + mt.x_control[e]);
-    add_M_own(tm + th.to[TH_E_TT][e]);
-    add_M_theta(y_y + mt.y_dyn[ch], tm + th.to[TH_E_DYN][e], nc);
-    add_MT_v(tm + th.to[TH_E_DYN][e], nc, x_y + mt.y_dyn[ch]);
-    add_M_theta(y_y + mt.y_edge_c[e], tm + th.to[TH_E_C][e], c);
-    add_MT_v(tm + th.to[TH_E_C][e], c, x_y + mt.y_edge_c[e]);
-    add_M_theta(y_z + mt.z_edge[e], tm + th.to[TH_E_G][e], g);
-    add_MT_v(tm + th.to[TH_E_G][e], g, x_z + mt.z_edge[e]);
+    if (pH) {
+      add_M_theta(y_x + mt.x_state[pa], tm + th.to[TH_E_X][e], n);
+      add_M_theta(y_x + mt.x_control[e], tm + th.to[TH_E_U][e], m);
+      add_MT_v(tm + th.to[TH_E_X][e], n, x_x + mt.x_state[pa]);
+      add_MT_v(tm + th.to[TH_E_U][e], m, x_x + mt.x_control[e]);
+      add_M_own(tm + th.to[TH_E_TT][e]);
+    }
+    if (pC)
+      add_M_theta(y_y + mt.y_dyn[ch], tm + th.to[TH_E_DYN][e], nc);
+    if (pCT)
+      add_MT_v(tm + th.to[TH_E_DYN][e], nc, x_y + mt.y_dyn[ch]);
+    if (pC)
+      add_M_theta(y_y + mt.y_edge_c[e], tm + th.to[TH_E_C][e], c);
+    if (pCT)
+      add_MT_v(tm + th.to[TH_E_C][e], c, x_y + mt.y_edge_c[e]);
+    if (pG)
+      add_M_theta(y_z + mt.z_edge[e], tm + th.to[TH_E_G][e], g);
+    if (pGT)
+      add_MT_v(tm + th.to[TH_E_G][e], g, x_z + mt.z_edge[e]);
     __syncthreads(); // sibling edges add to the same parent rows
   }
-  if (tid < p)
-    y_theta[tid] += yt + r1_all[prob * (sx + p) + sx + tid] * theta[tid];
+  if (tid < p && (pH || pCT || pGT || pR))
+    y_theta[tid] += pR ? yt + r1_all[prob * (sx + p) + sx + tid] * theta[tid] : yt;
 }
 
 } // namespace kkt

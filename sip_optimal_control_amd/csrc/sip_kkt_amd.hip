@@ -219,6 +219,60 @@ hipError_t launch_recover(const sip_kkt_plan *p, const Regions &r, const double 
   return hipGetLastError();
 }
 
+// [x | theta | y | z] vectors of the add_Kx_to_y entry points as an ApplyIO (all blocks).
+sipamd::kkt::ApplyIO kkt_vector_io(const sip_kkt_plan *p, int theta_dim, const double *d_x, double *d_y) {
+  const long xt = (long)p->x_dim + theta_dim, full = xt + p->y_dim + p->z_dim;
+  sipamd::kkt::ApplyIO io;
+  io.x_x = d_x, io.x_y = d_x + xt, io.x_z = d_x + xt + p->y_dim;
+  io.y_x = d_y, io.y_y = d_y + xt, io.y_z = d_y + xt + p->y_dim;
+  io.sx = io.sy = io.sz = full;
+  io.parts = sipamd::kkt::AP_ALL;
+  return io;
+}
+
+// y += (selected blocks of K) x.  d_theta != nullptr: x-space vectors carry theta behind the
+// stagewise x and the theta sections of the operators are added (apply_theta_kernel).
+int apply_blocks(const sip_kkt_plan *p, const double *d_model, const double *d_theta, const double *d_w,
+                 const double *d_r1, const double *d_r2, const double *d_r3, const sipamd::kkt::ApplyIO &io,
+                 hipStream_t s, const char *what) {
+  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, what);
+  const int th = d_theta != nullptr ? p->theta_dim : 0;
+  if (p->chain_kernels) {
+    hipLaunchKernelGGL(sipamd::kkt::apply_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                       p->lds_chain_apply, s, p->ck, th, d_model, d_w, d_r1, d_r2, d_r3, io, (long)p->batch);
+  } else {
+    sipamd::kkt::Meta wide = p->meta; // x-space = [stagewise x | theta]
+    wide.theta_dim = th;
+    hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, wide, d_model,
+                       d_w, d_r1, d_r2, d_r3, io, (long)p->batch);
+  }
+  if (th > 0)
+    hipLaunchKernelGGL(sipamd::kkt::apply_theta_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB), 0, s,
+                       p->meta, p->theta_meta, d_theta, d_r1, io, (long)p->batch);
+  return report(hipGetLastError(), what);
+}
+
+// One of the five block operators: xs / ys = vector space of x / y (0 x-space, 1 y-space, 2 z-space).
+int block_op(const sip_kkt_plan *p, const double *d_model, const double *d_theta, int part, int xs, int ys,
+             const double *d_x, double *d_y, hipStream_t s, const char *what) {
+  if (p == nullptr || p->input_status != SIP_KKT_SUCCESS)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  const int th = d_theta != nullptr ? p->theta_dim : 0;
+  const long len[3] = {(long)p->x_dim + th, (long)p->y_dim, (long)p->z_dim};
+  if (len[xs] == 0 || len[ys] == 0)
+    return SIP_LQR_OK; // an empty space: nothing to add
+  if ((!d_model && p->model_len > 0) || !d_x || !d_y)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sipamd::kkt::ApplyIO io{};
+  io.sx = len[0], io.sy = len[1], io.sz = len[2];
+  (xs == 0 ? io.x_x : xs == 1 ? io.x_y : io.x_z) = d_x;
+  (ys == 0 ? io.y_x : ys == 1 ? io.y_y : io.y_z) = d_y;
+  io.parts = part;
+  return apply_blocks(p, d_model, d_theta, nullptr, nullptr, nullptr, nullptr, io, s, what);
+}
+
 int fill_status(const sip_kkt_plan *p, int32_t *d_status, hipStream_t s) {
   std::vector<int32_t> st((size_t)p->batch, p->input_status);
   if (hipMemcpyAsync(d_status, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -624,18 +678,30 @@ int sip_kkt_add_Kx_to_y(const sip_kkt_plan *p, const double *d_model, const doub
   if ((!d_model && p->model_len > 0) || (!d_w && p->z_dim > 0) || (!d_r1 && p->x_dim > 0) ||
       (!d_r2 && p->y_dim > 0) || (!d_r3 && p->z_dim > 0) || !d_x || !d_y)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
-  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
-  if (on_device.err != hipSuccess)
-    return report(on_device.err, "sip_kkt_add_Kx_to_y(hipSetDevice)");
-  if (p->chain_kernels)
-    hipLaunchKernelGGL(sipamd::kkt::apply_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_apply, (hipStream_t)stream, p->ck, 0, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y,
-                       (long)p->batch);
-  else
-    hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0,
-                       (hipStream_t)stream, p->meta, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
-  return report(hipGetLastError(), "sip_kkt_add_Kx_to_y");
+  return apply_blocks(p, d_model, nullptr, d_w, d_r1, d_r2, d_r3, kkt_vector_io(p, 0, d_x, d_y), (hipStream_t)stream,
+                      "sip_kkt_add_Kx_to_y");
 }
+
+// The five block operators (helpers.hpp:20-24): one bit of ApplyPart each, vectors by space.
+#define SIP_KKT_BLOCK_OP(NAME, PART, XS, YS)                                                                 \
+  int sip_kkt_add_##NAME##_to_y(const sip_kkt_plan *p, const double *d_model, const double *d_x, double *d_y,  \
+                                void *stream) {                                                              \
+    return block_op(p, d_model, nullptr, sipamd::kkt::PART, XS, YS, d_x, d_y, (hipStream_t)stream,            \
+                    "sip_kkt_add_" #NAME "_to_y");                                                           \
+  }                                                                                                          \
+  int sip_kkt_add_##NAME##_to_y_theta(const sip_kkt_plan *p, const double *d_model, const double *d_theta,     \
+                                      const double *d_x, double *d_y, void *stream) {                        \
+    if (p == nullptr || p->theta_dim < 1 || d_theta == nullptr)                                             \
+      return SIP_LQR_ERR_INVALID_ARGUMENT;                                                                   \
+    return block_op(p, d_model, d_theta, sipamd::kkt::PART, XS, YS, d_x, d_y, (hipStream_t)stream,            \
+                    "sip_kkt_add_" #NAME "_to_y_theta");                                                     \
+  }
+SIP_KKT_BLOCK_OP(Hx, AP_H, 0, 0)
+SIP_KKT_BLOCK_OP(Cx, AP_C, 0, 1)
+SIP_KKT_BLOCK_OP(CTx, AP_CT, 1, 0)
+SIP_KKT_BLOCK_OP(Gx, AP_G, 0, 2)
+SIP_KKT_BLOCK_OP(GTx, AP_GT, 2, 0)
+#undef SIP_KKT_BLOCK_OP
 
 } // extern "C"
 
@@ -829,23 +895,9 @@ int sip_kkt_add_Kx_to_y_theta(const sip_kkt_plan *p, const double *d_model, cons
                               const double *d_x, double *d_y, void *stream) {
   if (p == nullptr || p->theta_dim < 1 || !d_theta || !d_r1 || !d_x || !d_y)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
-  sipamd::DeviceGuard on_device(p->device); // launch on the plan's device, whatever the caller's current one
-  if (on_device.err != hipSuccess)
-    return report(on_device.err, "sip_kkt_add_Kx_to_y_theta(hipSetDevice)");
-  hipStream_t s = (hipStream_t)stream;
-  if (p->chain_kernels) {
-    hipLaunchKernelGGL(sipamd::kkt::apply_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_apply, s, p->ck, p->theta_dim, d_model, d_w, d_r1, d_r2, d_r3, d_x, d_y,
-                       (long)p->batch);
-  } else {
-    sipamd::kkt::Meta wide = p->meta; // the stagewise operator on [x | theta | y | z] vectors
-    wide.theta_dim = p->theta_dim;
-    hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, wide, d_model,
-                       d_w, d_r1, d_r2, d_r3, d_x, d_y, (long)p->batch);
-  }
-  hipLaunchKernelGGL(sipamd::kkt::apply_theta_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB), 0, s, p->meta,
-                     p->theta_meta, d_theta, d_r1, d_x, d_y, (long)p->batch);
-  return report(hipGetLastError(), "sip_kkt_add_Kx_to_y_theta");
+  // the stagewise operator on [x | theta | y | z] vectors, then the theta terms
+  return apply_blocks(p, d_model, d_theta, d_w, d_r1, d_r2, d_r3, kkt_vector_io(p, p->theta_dim, d_x, d_y),
+                      (hipStream_t)stream, "sip_kkt_add_Kx_to_y_theta");
 }
 
 } // extern "C"

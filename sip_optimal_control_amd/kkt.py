@@ -113,6 +113,30 @@ class BatchedNewtonKKT:
                                              self._ptr(y, self.kkt_dim), self._stream()), "sip_kkt_add_Kx_to_y")
         return y
 
+    # ---- the five block operators (CallbackProvider::add_{H,C,CT,G,GT}x_to_y, helpers.hpp:20-24) ----
+    BLOCK_SPACES = {"Hx": ("x", "x"), "Cx": ("x", "y"), "CTx": ("y", "x"), "Gx": ("x", "z"), "GTx": ("z", "x")}
+
+    def space_dim(self, space, theta=False):
+        return {"x": self.x_dim + (self.theta_dim if theta else 0), "y": self.y_dim, "z": self.z_dim}[space]
+
+    def add_block_to_y(self, name, model, x, y=None, theta_model=None):
+        """y += (block) x for name in BLOCK_SPACES; vectors are [batch, len of their space]; with
+        theta_model the x-space vectors are [stagewise x | theta]."""
+        src, dst = self.BLOCK_SPACES[name]
+        theta = theta_model is not None
+        if y is None:
+            y = torch.zeros(self.batch, self.space_dim(dst, theta), dtype=torch.float64, device=self.device)
+        xs, ys = self._ptr(x, self.space_dim(src, theta)), self._ptr(y, self.space_dim(dst, theta))
+        if theta:
+            fn = getattr(self._lib, f"sip_kkt_add_{name}_to_y_theta")
+            _check(fn(self._plan, self._ptr(model, self.model_len), self._ptr(theta_model, self.theta_len), xs, ys,
+                      self._stream()), f"sip_kkt_add_{name}_to_y_theta")
+        else:
+            fn = getattr(self._lib, f"sip_kkt_add_{name}_to_y")
+            _check(fn(self._plan, self._ptr(model, self.model_len), xs, ys, self._stream()),
+                   f"sip_kkt_add_{name}_to_y")
+        return y
+
     # ---- theta_dim > 0: r1 is [batch, x_dim + p], b / sol / x / y are [batch, full_dim] ----
     def theta_offset(self, block, index):
         off = self._lib.sip_kkt_theta_offset(self._plan, block, index)

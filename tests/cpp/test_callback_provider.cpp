@@ -102,6 +102,31 @@ static void expect_kkt_solve(const Input &input, Workspace &workspace, double to
     sq += (pz[i] - rhs[x_dim + y_dim + i]) * (pz[i] - rhs[x_dim + y_dim + i]);
   std::printf("    kkt_dim %d  ||K sol - rhs|| = %.3e (tolerance %.0e)\n", kkt_dim, std::sqrt(sq), tolerance);
   CHECK(std::sqrt(sq) < tolerance);
+  // The same product from the five block operators, composed exactly as CallbackProvider::add_Kx_to_y
+  // composes them (helpers.cpp:953-976): what SIP does with the callbacks it is handed one by one
+  // (sip_optimal_control.cpp:147-190).
+  std::vector<double> qx(x_dim + 1, 0.0), qy(y_dim + 1, 0.0), qz(z_dim + 1, 0.0);
+  const double *x_x = solution.data(), *x_y = solution.data() + x_dim, *x_z = solution.data() + x_dim + y_dim;
+  callback_provider.add_Hx_to_y(x_x, qx.data());
+  callback_provider.add_Cx_to_y(x_x, qy.data());
+  callback_provider.add_CTx_to_y(x_y, qx.data());
+  callback_provider.add_Gx_to_y(x_x, qz.data());
+  callback_provider.add_GTx_to_y(x_z, qx.data());
+  for (int i = 0; i < x_dim; ++i)
+    qx[i] += r1[i] * x_x[i];
+  for (int i = 0; i < y_dim; ++i)
+    qy[i] -= r2[i] * x_y[i];
+  for (int i = 0; i < z_dim; ++i)
+    qz[i] -= (w[i] + r3[i]) * x_z[i];
+  double dq = 0.0;
+  for (int i = 0; i < x_dim; ++i)
+    dq = std::fmax(dq, std::fabs(qx[i] - px[i]));
+  for (int i = 0; i < y_dim; ++i)
+    dq = std::fmax(dq, std::fabs(qy[i] - py[i]));
+  for (int i = 0; i < z_dim; ++i)
+    dq = std::fmax(dq, std::fabs(qz[i] - pz[i]));
+  std::printf("    five block operators + diagonal vs add_Kx_to_y: max |diff| = %.3e\n", dq);
+  CHECK(dq < 1e-12);
 }
 
 struct Case {

@@ -3,7 +3,7 @@ u = k + K x (lqr.cpp:856-857) of INDEPENDENT dense-KKT solutions of the same pro
 offsets c[j] (see that file for why this pins K and k completely), and, at the full BASELINE sizes,
 of the kernel's own (KKT-residual-checked) x and u.
 
-fp64: 1e-9 (relative to max |u|).  fp32 (C4 kernel, problem rounded to fp32 first): 2e-3, the stated
+fp64: 1e-9 (relative to max |u|).  fp32 (C4 kernel, problem rounded to fp32 first): 1e-4, the stated
 fp32 tolerance of tests/test_gpu_mf32_parity.py (measured value printed)."""
 import glob
 import os
@@ -41,13 +41,13 @@ def test_hip_gains_are_the_control_law_of_the_dense_kkt_solutions(path):
     defect, margin = fam.defect(gains[0].double().cpu().numpy())
     print(f"{os.path.basename(path)} {solver.kernel_name}: control-law defect {defect:.2e}, margin {margin:.1e}")
     assert margin > 1e-6
-    assert defect <= (2e-3 if f32 else 1e-9), defect
+    assert defect <= (1e-4 if f32 else 1e-9), defect
     # split entry point: the gains of sip_lqr_factor alone (K only; k comes with solve)
     g2, st2 = solver.factor(mats)
     solver.solve(mats, vecs, g2)
     torch.cuda.synchronize()
     defect2, _ = fam.defect(g2[0].double().cpu().numpy())
-    assert defect2 <= (2e-3 if f32 else 1e-9), defect2
+    assert defect2 <= (1e-4 if f32 else 1e-9), defect2
 
 
 @pytest.mark.parametrize("name", ["nonuniform_diagonal_delta", "branch_tree", "variable_dimension_branch",
@@ -94,4 +94,4 @@ def test_full_size_solution_obeys_its_own_gains(workload):
     assert bool((status == 0).all())
     defect = _own_control_law_defect(n, m, T, sol.double(), gains.double())
     print(f"{workload}: own control-law defect {defect:.2e}")
-    assert defect <= (2e-4 if dtype == torch.float32 else 1e-12), defect
+    assert defect <= (1e-5 if dtype == torch.float32 else 1e-12), defect

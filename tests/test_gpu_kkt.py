@@ -395,3 +395,60 @@ def test_step_is_hip_graph_capturable():
         assert st.tolist() == [0] * batch
         assert (np.abs(sol.cpu().numpy() - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= REL
         assert torch.equal(lsol, eager_lqr)
+
+
+def _block_problem(name, batch):
+    """(dims, [model, w, r1, r2, r3, rhs] per-batch arrays, theta_model or None)."""
+    if name in rk.REFERENCE_CASES:
+        dims, model, reg = rk.reference_case(name)
+        return dims, _batchify(batch, model, *reg), None
+    if name == "schur":
+        dims, model, theta_model, reg = rk.schur_case()
+        arrays = _batchify(batch, model, *reg)
+        return dims, arrays, _batchify(batch, theta_model)[0]
+    n, m, T, p = {"chain": (12, 4, 9, 0), "chain_theta": (6, 2, 10, 4), "chain_wide": (20, 3, 5, 0)}[name]
+    dims = rk.newton_kkt_dims(n, m, T)
+    if p:
+        dims = rk.KKTDims(dims.parents, dims.children, dims.sd, dims.cd, dims.ncd, dims.ngd, dims.ecd, dims.egd,
+                          theta_dim=p)
+    out = rk.newton_kkt_problem(dims, seed=31 + n, batch=batch, r2_max=1e2)
+    return dims, list(out[:6]), (out[6] if p else None)
+
+
+@pytest.mark.parametrize("name", sorted(rk.REFERENCE_CASES) + ["schur", "chain", "chain_theta", "chain_wide"])
+def test_block_operators(name):
+    """sip_kkt_add_{Hx,Cx,CTx,Gx,GTx}_to_y (CallbackProvider::add_*x_to_y, helpers.hpp:20-24, bodies
+    helpers.cpp:978-1368; the callbacks SIP gets one by one, sip_optimal_control.cpp:147-190) on the
+    reference's four CallbackProvider cases (tests/variable_dimensions_test.cpp:265-363: chain,
+    sibling edges, zero-dimensional root, Schur variables) and on benchmark chains (LDS-staged chain
+    kernel; with theta; n > 16), against the oracle's restatement of each body: they accumulate
+    (y += ...), and summed with the regularization diagonal they are add_Kx_to_y (helpers.cpp:953-976)."""
+    batch = 5
+    dims, arrays, theta_model = _block_problem(name, batch)
+    model, w, r1, r2, r3 = arrays[:5]
+    kkt = _make(dims, batch)
+    if name in ("chain", "chain_theta", "chain_wide"):
+        assert "chain condensation" in kkt.kernel_name
+    o = KKTOracle(dims)
+    rng = np.random.default_rng(17)
+    theta = theta_model is not None
+    d_model, d_theta = _dev(model)[0], (_dev(theta_model)[0] if theta else None)
+    vec = {s: rng.standard_normal((batch, kkt.space_dim(s, theta))) for s in "xyz"}
+    parts = {}
+    for op, (src, dst) in kkt.BLOCK_SPACES.items():
+        y0 = rng.standard_normal((batch, kkt.space_dim(dst, theta)))
+        got = kkt.add_block_to_y(op, d_model, _dev(vec[src])[0], y=_dev(y0)[0], theta_model=d_theta).cpu().numpy()
+        for p in range(batch):
+            ref = o.add_block_to_y(op, model[p], vec[src][p], y=y0[p], theta_model=theta_model[p] if theta else None)
+            scale = max(1.0, np.abs(ref).max(initial=0.0))
+            assert np.abs(got[p] - ref).max(initial=0.0) <= REL * scale, (op, p)
+        parts[op] = got - y0
+    # the five blocks and the diagonal add up to the whole operator, as computed by the GPU's add_Kx_to_y
+    full = np.concatenate([vec["x"], vec["y"], vec["z"]], axis=1)
+    if theta:
+        whole = kkt.add_Kx_to_y_theta(d_model, d_theta, *_dev(w, r1, r2, r3, full)).cpu().numpy()
+    else:
+        whole = kkt.add_Kx_to_y(d_model, *_dev(w, r1, r2, r3, full)).cpu().numpy()
+    want = np.concatenate([parts["Hx"] + parts["CTx"] + parts["GTx"] + r1 * vec["x"], parts["Cx"] - r2 * vec["y"],
+                           parts["Gx"] - (w + r3) * vec["z"]], axis=1)
+    assert np.abs(whole - want).max() <= REL * max(1.0, np.abs(want).max())

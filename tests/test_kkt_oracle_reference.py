@@ -181,3 +181,49 @@ def test_theta_on_a_benchmark_chain():
     K = dense_kkt_matrix(dims, model, w, r1, r2, r3, theta_model)
     dense = np.linalg.solve(K, rhs)
     assert np.linalg.norm(sol - dense) <= 1e-8 * np.linalg.norm(dense)
+
+
+def _block_case(name):
+    if name == "schur":
+        dims, model, theta_model, reg = rk.schur_case()
+    elif name == "theta_chain":
+        base = rk.newton_kkt_dims(6, 2, 10)
+        dims = KKTDims(base.parents, base.children, base.sd, base.cd, base.ncd, base.ngd, base.ecd, base.egd,
+                       theta_dim=4)
+        model, w, r1, r2, r3, rhs, theta_model = rk.newton_kkt_problem(dims, seed=9, r2_max=1e2)
+        reg = (w, r1, r2, r3, rhs)
+    else:
+        dims, model, reg = rk.reference_case(name)
+        theta_model = None
+    return dims, model, theta_model, reg
+
+
+@pytest.mark.parametrize("name", sorted(rk.REFERENCE_CASES) + ["schur", "theta_chain"])
+def test_block_operators_match_dense_blocks_and_compose_to_K(name):
+    """add_Hx / Cx / CTx / Gx / GTx_to_y (helpers.hpp:20-24, bodies helpers.cpp:978-1368) on the
+    reference's four CallbackProvider cases (tests/variable_dimensions_test.cpp:265-363) and a
+    benchmark chain with theta: each equals its dense block times x, accumulates (y += ...), and the
+    five together with the regularization diagonal are add_Kx_to_y (helpers.cpp:953-976)."""
+    from oracle.kkt import dense_kkt_blocks
+    dims, model, theta_model, (w, r1, r2, r3, _) = _block_case(name)
+    o = KKTOracle(dims)
+    H, C, G = dense_kkt_blocks(dims, model, theta_model)
+    rng = np.random.default_rng(3)
+    xd, yd, zd = dims.x_dim + dims.p, dims.y_dim, dims.z_dim
+    vx, vy, vz = rng.standard_normal(xd), rng.standard_normal(yd), rng.standard_normal(zd)
+    mats = {"Hx": (H, vx), "Cx": (C, vx), "CTx": (C.T, vy), "Gx": (G, vx), "GTx": (G.T, vz)}
+    outs = {}
+    for op, (mat, vec) in mats.items():
+        y0 = rng.standard_normal(mat.shape[0])
+        got = o.add_block_to_y(op, model, vec, y=y0, theta_model=theta_model)
+        np.testing.assert_allclose(got, y0 + mat @ vec, rtol=0, atol=1e-12, err_msg=op)
+        outs[op] = got - y0
+    # composition: K [vx; vy; vz]
+    full = np.concatenate([vx, vy, vz])
+    want_x = outs["Hx"] + outs["CTx"] + outs["GTx"] + r1 * vx
+    want = np.concatenate([want_x, outs["Cx"] - r2 * vy, outs["Gx"] - (w + r3) * vz])
+    if dims.p > 0:
+        got = o.add_Kx_to_y_theta(model, theta_model, w, r1, r2, r3, full)
+    else:
+        got = o.add_Kx_to_y(model, w, r1, r2, r3, full)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
