@@ -41,11 +41,36 @@ def parse_args():
                          "the sweep (SURVEY.md 8 row f1, NewtonKKTProblem(12, 4, 50), batch 4096)")
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-gather", action="store_true",
-                    help="multi-GPU: skip the RCCL all-gather of the gains")
+                    help="multi-GPU: skip the RCCL all-gather of the gains (the default N > 1 run reports "
+                         "both: `value` with the gather, `no_gather` beside it)")
+    ap.add_argument("--gather-chunks", type=int, default=8,
+                    help="multi-GPU: chunk gathers per sweep (SURVEY.md 8(e): 8 x 512 problems)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target wall time of each cpu_baseline leg")
     return ap.parse_args()
+
+
+def library_version():
+    """'sip_lqr_amd <ver> (gfx950) SIPLQRSRC=<sha256 of the sources the library was built from>'."""
+    from sip_optimal_control_amd._lib import load_library
+    return load_library().sip_lqr_version().decode()
+
+
+def recorded_traffic(key):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), with where they come
+    from: counters are collected in separate rocprofv3 --pmc runs (tools/profile_gpu.sh), never inside a
+    bench run, so the line says so instead of passing the number off as measured live."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path)).get(key)
+    except Exception:
+        rec = None
+    if not rec:
+        return None, None
+    src = (f"profiles/traffic.json[{key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+           f"({rec.get('profile', 'source file not recorded')}), NOT measured in this run")
+    return rec["hbm_bytes_per_launch"], src
 
 
 def usable_cores():
@@ -150,6 +175,7 @@ def kkt_main(args):
     ms = elapsed / args.steps * 1e3
     alg_bytes = 8 * (kkt.model_len + 2 * kkt.z_dim + kkt.x_dim + kkt.y_dim + 2 * kkt.kkt_dim)
     achieved = batch * alg_bytes / (ms * 1e-3) / 1e9
+    kkt_traffic, kkt_traffic_src = recorded_traffic(f"kkt:{kkt.kernel_name}") if batch == 4096 else (None, None)
     out = {
         "metric": "Newton-KKT factor+solves/sec", "value": batch * args.steps / elapsed, "unit": "solves/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -159,9 +185,10 @@ def kkt_main(args):
         # whole step (3 launches + the Riccati sweep): algorithmic bytes = model + w, r1, r2, r3, b read
         # once + sol written once; PMC traffic of the step in profiles/r01_kkt/traffic_end.md
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": 4.802e9 if batch == 4096 else None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": kkt_traffic, "traffic_source": kkt_traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes * batch},
     }
+    out["config"]["library"] = library_version()
     if not args.no_cpu_baseline:
         out["cpu_baseline"], ref = kkt_cpu_baseline(dims, data, args.cpu_seconds)
         got = sol[:ref.shape[0]].cpu().numpy()
@@ -206,64 +233,67 @@ def main():
     solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device=device)
     sol = solver.empty_sol()
     gather = world > 1 and not args.no_gather
-    if gather:
-        ag = GainsAllGather(batch, shape.gains_len, dtype, device)
-    else:
-        gains = [solver.empty_gains(), solver.empty_gains()]
+    ag = GainsAllGather(batch, shape.gains_len, dtype, device, chunks=min(args.gather_chunks, batch)) if gather else None
+    gains = [solver.empty_gains(), solver.empty_gains()]
 
     compute = torch.cuda.current_stream(device)
-    kernel_events = []
-
-    def step(i, timed):
-        # gains are double-buffered; with the gather on, buffer i%2 is only
-        # rewritten once the all-gather of sweep i-2 has drained it
-        out_gains = ag.acquire(i) if gather else gains[i & 1]
-        if timed:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(compute)
-        solver.factor_solve(mats, vecs, sol, out_gains)
-        if timed:
-            e1.record(compute)
-            kernel_events.append((e0, e1))
-        if gather:
-            ag.launch(i)  # RCCL all-gather on the side stream, overlaps sweep i+1
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for i in range(args.warmup):
-        step(i, False)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, True)
-    if gather:
-        ag.finish()
-    torch.cuda.synchronize(device)
-    elapsed_local = time.perf_counter() - t0
-    fence()
-    el = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    def run(with_gather):
+        """W warmup steps, then exactly K timed steps between barrier + synchronize fences; returns
+        (max-over-ranks seconds, mean kernel ms of this rank)."""
+        events = []
+
+        def step(i, timed):
+            # gains are double-buffered; with the gather on, buffer i%2 is only rewritten once every
+            # chunk gather of sweep i-2 has drained it
+            out_gains = ag.acquire(i) if with_gather else gains[i & 1]
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(compute)
+            solver.factor_solve(mats, vecs, sol, out_gains)
+            if timed:
+                e1.record(compute)
+                events.append((e0, e1))
+            if with_gather:
+                ag.mark_ready(i)  # one launch produces every chunk: all chunks ready behind it
+                ag.launch(i)      # chunk gathers on the side stream, overlapping sweep i+1
+
+        for i in range(args.warmup):
+            step(i, False)
+        if with_gather:
+            ag.finish()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, True)
+        if with_gather:
+            ag.finish()
+        torch.cuda.synchronize(device)
+        local = time.perf_counter() - t0
+        fence()
+        el = torch.tensor([local], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+
+    elapsed, kernel_ms = run(gather)
+    no_gather = None
+    if gather:  # the same K steps without the exchange: independent shards, the compute-only bound
+        ng_elapsed, ng_kernel_ms = run(False)
+        no_gather = {"value": world * batch * args.steps / ng_elapsed, "unit": "sweeps/s",
+                     "ms_per_step": ng_elapsed / args.steps * 1e3, "kernel_ms": ng_kernel_ms}
 
     status_ok = bool((solver.status == 0).all().item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))
-
     if rank == 0:
         alg_bytes = shape.algorithmic_bytes(esize)
         achieved = alg_bytes * batch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                rec = json.load(open(tpath)).get(f"{args.workload}:{solver.kernel_name}")
-                traffic = rec["hbm_bytes_per_launch"] if rec else None
-            except Exception:
-                traffic = None
+        traffic, traffic_src = recorded_traffic(f"{args.workload}:{solver.kernel_name}")
         out = {
             "metric": "Riccati sweeps/sec (backward+forward)",
             "value": world * batch * args.steps / elapsed,
@@ -281,12 +311,13 @@ def main():
                 "workload": f"{args.workload}: batch={batch}/GPU x horizon={T}, nx={n}, nu={m}, {dt}, "
                             f"chain, fused factor+solve" + (", RCCL all-gather of gains" if gather else ""),
                 "global_batch": world * batch, "horizon": T, "nx": n, "nu": m,
-                "parallelism": f"batch-sharded x{world}" + ("+allgather(K,k)" if gather else ""),
-                "kernel": solver.kernel_name, "all_status_success": status_ok,
+                "parallelism": f"batch-sharded x{world}" +
+                               (f"+allgather(K,k) in {ag.chunks} chunks/sweep" if gather else ""),
+                "kernel": solver.kernel_name, "all_status_success": status_ok, "library": library_version(),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes * batch,
                 # rate of the bytes the kernel really moves (PMC traffic / live launch time);
                 # MI355X_MICROARCH.md: a float4 copy sustains ~6.3 TB/s on this part
@@ -299,10 +330,16 @@ def main():
             tflops = shape.algorithmic_flops() * batch / (kernel_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s",
-                "frac": tflops / 157.3, "traffic": traffic, "kernel_ms": kernel_ms,
+                "frac": tflops / 157.3, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": shape.algorithmic_flops() * batch,
                 "hbm_achieved_gbs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
             }
+        if gather:
+            # per sweep every rank sends its shard and receives (world - 1) shards of gains over xGMI
+            shard = batch * shape.gains_len * esize
+            out["gather"] = {"bytes_received_per_rank_per_sweep": (world - 1) * shard, "chunks": ag.chunks,
+                             "kernel_ms_beside_the_gather": kernel_ms}
+            out["no_gather"] = no_gather
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, mats, vecs, args.cpu_seconds)
         print(json.dumps(out), flush=True)

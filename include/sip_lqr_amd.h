@@ -116,6 +116,9 @@ size_t sip_lqr_sol_bytes(const sip_lqr_plan *plan);
 size_t sip_lqr_gains_bytes(const sip_lqr_plan *plan);
 size_t sip_lqr_status_bytes(const sip_lqr_plan *plan);
 size_t sip_lqr_workspace_bytes(const sip_lqr_plan *plan);
+/* Problems per call and bytes per scalar (8: SIP_LQR_F64, 4: SIP_LQR_F32) of a plan. */
+int64_t sip_lqr_plan_batch(const sip_lqr_plan *plan);
+size_t sip_lqr_scalar_bytes(const sip_lqr_plan *plan);
 /* Per-problem lengths in scalars (packed chain layout above). */
 size_t sip_lqr_mats_len(const sip_lqr_plan *plan);
 size_t sip_lqr_vecs_len(const sip_lqr_plan *plan);

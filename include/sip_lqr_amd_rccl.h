@@ -46,6 +46,35 @@ int sip_lqr_group_all_gather_gains(sip_lqr_group *group, const sip_lqr_plan *con
 int sip_lqr_all_gather_gains(const sip_lqr_plan *plan, void *nccl_comm, const void *d_gains,
                              void *d_all_gains, void *stream);
 
+/* ---- chunk-pipelined exchange -----------------------------------------
+ * The shard of a rank is cut into `num_chunks` contiguous problem ranges (sip_lqr_gains_chunk_range:
+ * equal sizes, the last ones one problem smaller when it does not divide; identical on every rank),
+ * and chunk c of every rank is gathered by its own collective, which the caller enqueues behind
+ * whatever produced that chunk's gains (an event behind the sweep, or behind one of several
+ * sub-batch launches) while later chunks / the next sweep still compute.  Collectives must be
+ * issued in the same order on every rank: enqueue the chunks of a sweep in chunk order.
+ * Gathered layout: chunk-major, the bytes of (rank r, chunk c) at sip_lqr_gains_chunk_offset(): what
+ * one ncclAllGather per chunk produces with no re-packing. */
+int sip_lqr_gains_chunk_range(const sip_lqr_plan *plan, int chunk, int num_chunks, int64_t *first_problem,
+                              int64_t *num_problems);
+size_t sip_lqr_gains_chunk_offset(const sip_lqr_plan *plan, int nranks, int rank, int chunk, int num_chunks);
+int sip_lqr_all_gather_gains_chunk(const sip_lqr_plan *plan, void *nccl_comm, int nranks, const void *d_gains,
+                                   void *d_all_gains, int chunk, int num_chunks, void *stream);
+int sip_lqr_group_all_gather_gains_chunk(sip_lqr_group *group, const sip_lqr_plan *const *plans,
+                                         const void *const *d_gains, void *const *d_all_gains, int chunk,
+                                         int num_chunks, void *const *streams);
+
+/* One-process groups: the same exchange as direct peer copies over the xGMI mesh, one copy per
+ * (rank, peer) pair on a stream of its own, so that the seven links of a GPU carry its shard to the
+ * seven peers at the same time (a ring would push the shard through one link seven times).  Rank-major
+ * layout, as sip_lqr_group_all_gather_gains.  Each copy waits for the work enqueued on streams[i] when
+ * the call is made, and streams[i] waits for the copies INTO rank i, so the usual stream semantics hold.
+ * Needs peer access between all devices of the group (enabled by sip_lqr_group_create where the
+ * hardware offers it; SIP_LQR_ERR_UNSUPPORTED otherwise). */
+int sip_lqr_group_all_gather_gains_p2p(sip_lqr_group *group, const sip_lqr_plan *const *plans,
+                                       const void *const *d_gains, void *const *d_all_gains,
+                                       void *const *streams);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,8 @@ _SIGNATURES = {
     "sip_lqr_gains_bytes": (ctypes.c_size_t, [_P]),
     "sip_lqr_status_bytes": (ctypes.c_size_t, [_P]),
     "sip_lqr_workspace_bytes": (ctypes.c_size_t, [_P]),
+    "sip_lqr_plan_batch": (ctypes.c_int64, [_P]),
+    "sip_lqr_scalar_bytes": (ctypes.c_size_t, [_P]),
     "sip_lqr_mats_len": (ctypes.c_size_t, [_P]),
     "sip_lqr_vecs_len": (ctypes.c_size_t, [_P]),
     "sip_lqr_gains_len": (ctypes.c_size_t, [_P]),

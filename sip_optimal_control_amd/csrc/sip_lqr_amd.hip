@@ -438,6 +438,8 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
 
 void sip_lqr_plan_destroy(sip_lqr_plan *plan) { delete plan; }
 
+int64_t sip_lqr_plan_batch(const sip_lqr_plan *p) { return p ? p->batch : 0; }
+size_t sip_lqr_scalar_bytes(const sip_lqr_plan *p) { return p ? scalar_size(p) : 0; }
 size_t sip_lqr_mats_len(const sip_lqr_plan *p) {
   const size_t n = p->n, m = p->m, T = p->T;
   return (T + 1) * (n * n + n) + T * (n * n + 2 * n * m + m * m);

@@ -3,11 +3,23 @@
 Problem instances are independent (no shared state between the reference's
 `LQR`/`Workspace` pairs), so the batch is block-partitioned over ranks with no
 data-path collective; the one exchange step is the all-gather of the feedback
-gains (K, k) -- one RCCL all-gather per sweep over xGMI (torch.distributed
-backend "nccl" is RCCL on ROCm), pipelined against the next sweep's compute:
-sweep i's gather runs on a side stream while sweep i+1 computes, with the gains
-double-buffered.  On CPU tensors (gloo, tests) the same object degrades to
-synchronous calls.
+gains (K, k) over RCCL / xGMI (torch.distributed backend "nccl" is RCCL on
+ROCm).
+
+The exchange of sweep i is cut into `chunks` contiguous problem ranges.  Chunk c
+is gathered as soon as ITS gains are final (`mark_ready(i, c)`: an event behind
+the launch that produced them -- the whole sweep, or one of several sub-batch
+launches), on a side stream, while the rest of sweep i and all of sweep i + 1
+compute; the gains are double-buffered, and a buffer is rewritten only once
+every chunk gather that reads it has drained.  Collectives have to be issued in
+one order on every rank, so the chunk gathers of a sweep are issued in chunk
+order 0 .. chunks-1 whatever the order in which the chunks became ready (each
+waits for its own event).  On CPU tensors (gloo; the tests) the same object
+runs with asynchronous work handles instead of streams.
+
+Layout of the gathered gains: chunk-major, `gathered[c][r]` = rows of rank r's
+chunk c (what one ncclAllGather per chunk produces without any re-packing);
+`rows_of(rank, chunk)` / `problem(global_index)` address it.
 """
 import torch
 import torch.distributed as dist
@@ -22,69 +34,135 @@ def shard_range(total, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class GainsAllGather:
-    """Double-buffered, stream-pipelined all-gather of per-rank gains."""
+def chunk_bounds(local_batch, chunks):
+    """[lo, hi) of every chunk of a shard: equal sizes (the last ones one smaller when it does not
+    divide); every rank must use the same (local_batch, chunks)."""
+    if chunks < 1 or chunks > max(1, local_batch):
+        raise ValueError("chunks must be in 1 .. local_batch")
+    return [shard_range(local_batch, chunks, c) for c in range(chunks)]
 
-    def __init__(self, local_batch, gains_len, dtype, device, group=None, depth=2):
+
+class GainsAllGather:
+    """Double-buffered, stream-pipelined, chunked all-gather of per-rank gains."""
+
+    def __init__(self, local_batch, gains_len, dtype, device, group=None, depth=2, chunks=1):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device)
         self.depth = depth
         self.on_gpu = self.device.type == "cuda"
+        self.local_batch, self.gains_len = local_batch, gains_len
+        self.bounds = chunk_bounds(local_batch, chunks)
+        self.chunks = chunks
         self.local = [torch.empty(local_batch, gains_len, dtype=dtype, device=self.device)
                       for _ in range(depth)]
+        # chunk-major: chunk c occupies rows [world * lo_c, world * hi_c), rank-major inside
         self.gathered = [torch.empty(self.world * local_batch, gains_len, dtype=dtype, device=self.device)
                          for _ in range(depth)]
-        self._done = [None] * depth
-        self._work = [None] * depth
+        self._ready = [[None] * chunks for _ in range(depth)]  # GPU: event behind the chunk's producer
+        self._done = [None] * depth                            # GPU: event behind the slot's last chunk gather
+        self._work = [[] for _ in range(depth)]                # CPU: async work handles of the slot
         self.comm_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
 
     def slot(self, i):
         return i % self.depth
 
+    # ---- addressing of the gathered buffer ------------------------------------------------------
+    def rows_of(self, rank, chunk):
+        """Row range of rank `rank`'s chunk `chunk` inside a gathered buffer."""
+        lo, hi = self.bounds[chunk]
+        base = self.world * lo + rank * (hi - lo)
+        return base, base + (hi - lo)
+
+    def problem(self, gathered, global_index):
+        """Gains row of global problem `global_index` (rank-major block partition of the batch)."""
+        rank, local = divmod(global_index, self.local_batch)
+        for c, (lo, hi) in enumerate(self.bounds):
+            if lo <= local < hi:
+                return gathered[self.rows_of(rank, c)[0] + (local - lo)]
+        raise IndexError(global_index)
+
+    def rank_major(self, gathered):
+        """A [world * local_batch, gains_len] copy in plain rank-major order (tests, consumers that
+        want the layout of one whole-shard all-gather)."""
+        if self.chunks == 1:
+            return gathered.clone()
+        parts = [gathered[slice(*self.rows_of(r, c))] for r in range(self.world) for c in range(self.chunks)]
+        return torch.cat(parts)
+
+    # ---- the pipeline --------------------------------------------------------------------------
     def acquire(self, i):
-        """Local gains buffer for sweep i, once the gather that last read it is done."""
+        """Local gains buffer for sweep i, once every gather that last read it is done."""
         s = self.slot(i)
         if self.on_gpu:
             if self._done[s] is not None:
                 torch.cuda.current_stream(self.device).wait_event(self._done[s])
-        elif self._work[s] is not None:
-            self._work[s].wait()
-            self._work[s] = None
+        else:
+            for w in self._work[s]:
+                w.wait()
+            self._work[s] = []
+        self._ready[s] = [None] * self.chunks
         return self.local[s]
 
-    def launch(self, i):
-        """Start the all-gather of sweep i's gains (after the compute enqueued so far)."""
+    def mark_ready(self, i, chunk=None):
+        """The gains of chunk `chunk` of sweep i (None: of every chunk) are final behind the work
+        enqueued so far on the current stream.  May be called in any chunk order."""
         s = self.slot(i)
+        which = range(self.chunks) if chunk is None else (chunk,)
+        ev = None
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        for c in which:
+            self._ready[s][c] = ev if self.on_gpu else True
+
+    def launch(self, i):
+        """Issue the chunk gathers of sweep i, in chunk order, each behind its own readiness.
+        Chunks not marked ready explicitly are taken to be ready behind the work enqueued so far."""
+        s = self.slot(i)
+        if any(r is None for r in self._ready[s]):
+            missing = [c for c, r in enumerate(self._ready[s]) if r is None]
+            for c in missing:
+                self.mark_ready(i, c)
+        out = self.gathered[s]
         if self.world == 1:
-            self.gathered[s].copy_(self.local[s])
-            return self.gathered[s]
+            out.copy_(self.local[s])
+            return out
         if self.on_gpu and dist.get_backend(self.group) != "nccl":
             # rehearsal backends (gloo) take host tensors: stage through the CPU, synchronously
             torch.cuda.current_stream(self.device).synchronize()
-            host = torch.empty(self.gathered[s].shape, dtype=self.gathered[s].dtype)
-            dist.all_gather_into_tensor(host, self.local[s].cpu(), group=self.group)
-            self.gathered[s].copy_(host)
+            for c, (lo, hi) in enumerate(self.bounds):
+                host = torch.empty(self.world * (hi - lo), self.gains_len, dtype=out.dtype)
+                dist.all_gather_into_tensor(host, self.local[s][lo:hi].cpu(), group=self.group)
+                out[self.world * lo:self.world * hi].copy_(host)
         elif self.on_gpu:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ready)
-                dist.all_gather_into_tensor(self.gathered[s], self.local[s], group=self.group)
+                for c, (lo, hi) in enumerate(self.bounds):
+                    self.comm_stream.wait_event(self._ready[s][c])
+                    dist.all_gather_into_tensor(out[self.world * lo:self.world * hi], self.local[s][lo:hi],
+                                                group=self.group)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
             self._done[s] = done
         else:
-            self._work[s] = dist.all_gather_into_tensor(self.gathered[s], self.local[s],
-                                                        group=self.group, async_op=True)
-        return self.gathered[s]
+            for c, (lo, hi) in enumerate(self.bounds):
+                self._work[s].append(dist.all_gather_into_tensor(out[self.world * lo:self.world * hi],
+                                                                 self.local[s][lo:hi], group=self.group,
+                                                                 async_op=True))
+        return out
+
+    def wait(self, i):
+        """Block (stream-wise on GPU) until the gathers of sweep i have landed."""
+        s = self.slot(i)
+        if self.on_gpu:
+            if self._done[s] is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._done[s])
+        else:
+            for w in self._work[s]:
+                w.wait()
+            self._work[s] = []
 
     def finish(self):
         """Block (stream-wise on GPU) until every outstanding gather has landed."""
         for s in range(self.depth):
-            if self.on_gpu:
-                if self._done[s] is not None:
-                    torch.cuda.current_stream(self.device).wait_event(self._done[s])
-            elif self._work[s] is not None:
-                self._work[s].wait()
-                self._work[s] = None
+            self.wait(s)

@@ -90,6 +90,42 @@ int main() {
     CHECK(host_gains[r][0] != 0.0);
   }
   std::printf("group of %d device(s): all-gather of %zu gains per rank ok\n", ndev, gl);
+  // the same exchange as direct peer copies (rank-major, like the collective above)
+  for (int r = 0; r < ndev; ++r)
+    CHECK(hipSetDevice(r) == hipSuccess && hipMemset(all[r], 0, gl * ndev * 8) == hipSuccess);
+  CHECK(sip_lqr_group_all_gather_gains_p2p(group, plans.data(), gains.data(), all.data(), streams.data()) == SIP_LQR_OK);
+  for (int r = 0; r < ndev; ++r) {
+    CHECK(hipSetDevice(r) == hipSuccess && hipDeviceSynchronize() == hipSuccess);
+    std::vector<double> got(gl * ndev);
+    CHECK(hipMemcpy(got.data(), all[r], gl * ndev * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    for (int q = 0; q < ndev; ++q)
+      CHECK(std::memcmp(got.data() + q * gl, host_gains[q].data(), gl * 8) == 0);
+  }
+  // chunk-pipelined form: 3 chunks of the 5-problem shard (2 + 2 + 1), chunk-major layout
+  const int chunks = 3;
+  const size_t per_problem = gl / batch;
+  int64_t lo = -1, cnt = -1;
+  CHECK(sip_lqr_gains_chunk_range(plans[0], 0, chunks, &lo, &cnt) == SIP_LQR_OK && lo == 0 && cnt == 2);
+  CHECK(sip_lqr_gains_chunk_range(plans[0], 2, chunks, &lo, &cnt) == SIP_LQR_OK && lo == 4 && cnt == 1);
+  CHECK(sip_lqr_gains_chunk_range(plans[0], 3, chunks, &lo, &cnt) == SIP_LQR_ERR_INVALID_ARGUMENT);
+  CHECK(sip_lqr_gains_chunk_offset(plans[0], ndev, 0, 1, chunks) == (size_t)ndev * 2 * per_problem * 8);
+  for (int r = 0; r < ndev; ++r)
+    CHECK(hipSetDevice(r) == hipSuccess && hipMemset(all[r], 0, gl * ndev * 8) == hipSuccess);
+  for (int c = 0; c < chunks; ++c)
+    CHECK(sip_lqr_group_all_gather_gains_chunk(group, plans.data(), gains.data(), all.data(), c, chunks,
+                                               streams.data()) == SIP_LQR_OK);
+  for (int r = 0; r < ndev; ++r) {
+    CHECK(hipSetDevice(r) == hipSuccess && hipDeviceSynchronize() == hipSuccess);
+    std::vector<double> got(gl * ndev);
+    CHECK(hipMemcpy(got.data(), all[r], gl * ndev * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    for (int q = 0; q < ndev; ++q)
+      for (int c = 0; c < chunks; ++c) {
+        CHECK(sip_lqr_gains_chunk_range(plans[q], c, chunks, &lo, &cnt) == SIP_LQR_OK);
+        const size_t at = sip_lqr_gains_chunk_offset(plans[q], ndev, q, c, chunks) / 8;
+        CHECK(std::memcmp(got.data() + at, host_gains[q].data() + lo * per_problem, cnt * per_problem * 8) == 0);
+      }
+  }
+  std::printf("direct peer copies and %d-chunk exchange ok\n", chunks);
   for (int r = 0; r < ndev; ++r)
     sip_lqr_plan_destroy(plans[r]);
   sip_lqr_group_destroy(group);
