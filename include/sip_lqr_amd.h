@@ -177,6 +177,25 @@ int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats,
                   const void *d_vecs, void *d_sol, void *d_gains,
                   void *d_workspace, void *stream);
 
+/* Replaces: the multi-right-hand-side block of solve_stagewise_kkt_matrix
+ * (helpers.cpp:521-665: LQR::solve generalised from one right-hand side to
+ * num_rhs columns, reading LQR::Workspace directly; the caller is the theta
+ * Schur complement, helpers.cpp:387) against the factor state of the last
+ * sip_lqr_factor() on the same workspace.  d_vecs_cols / d_sol_cols: num_rhs
+ * arrays of sip_lqr_vecs_bytes() each, one after the other (column c at
+ * c * sip_lqr_vecs_bytes()).  Shapes with a multi-rhs kernel (the fp64 shapes of
+ * the reference's benchmark grid) carry up to 8 columns through ONE backward /
+ * forward sweep, fetching every matrix operand of a stage once;
+ * d_col_workspace: sip_lqr_solve_multi_workspace_bytes() of device scratch
+ * (per-column g, h, k of the rollout).  Other shapes run sip_lqr_solve() per
+ * column (workspace bytes 0, d_col_workspace may be NULL).  The k part of
+ * d_gains is unspecified afterwards. */
+size_t sip_lqr_solve_multi_workspace_bytes(const sip_lqr_plan *plan, int num_rhs);
+int sip_lqr_solve_multi(const sip_lqr_plan *plan, const void *d_mats,
+                        const void *d_vecs_cols, void *d_sol_cols, int num_rhs,
+                        void *d_gains, void *d_workspace, void *d_col_workspace,
+                        void *stream);
+
 /* ------------------------------------------------------------------------
  * General trees / per-node dimensions (the full Topology + Dimensions model
  * of lqr.hpp:5-64): the path behind the drop-in C++ `LQR` adapter

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "sip_lqr_factor_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sip_lqr_factor": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "sip_lqr_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "sip_lqr_solve_multi_workspace_bytes": (ctypes.c_size_t, [_P, ctypes.c_int]),
+    "sip_lqr_solve_multi": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, _P, _P, _P]),
     "sip_lqr_compile_topology": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [_P] * 9),
     "sip_lqr_tree_plan_create": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P,
                                                 ctypes.c_int, _PP]),

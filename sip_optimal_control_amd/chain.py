@@ -125,6 +125,30 @@ class BatchedChainLQR:
             ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_solve")
         return sol
 
+    def solve_multi(self, mats, vecs_cols, gains, sol_cols=None, stream=None):
+        """LQR::solve() for several right-hand sides against the last factor() (the multi-rhs block of
+        solve_stagewise_kkt_matrix, helpers.cpp:521-665): vecs_cols / sol_cols are [num_rhs, batch,
+        vecs_len].  One sweep per 8 columns where the shape has the multi-rhs kernel."""
+        s = self.shape
+        num_rhs = vecs_cols.shape[0]
+        if sol_cols is None:
+            sol_cols = torch.empty(num_rhs, self.batch, s.vecs_len, dtype=self.dtype, device=self.device)
+        for t, name in ((vecs_cols, "vecs_cols"), (sol_cols, "sol_cols")):
+            if t.dtype != self.dtype or t.device != self.device or not t.is_contiguous() or \
+                    tuple(t.shape) != (num_rhs, self.batch, s.vecs_len):
+                raise ValueError(f"{name}: expected contiguous {self.dtype} [{num_rhs}, {self.batch}, {s.vecs_len}]")
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        need = self._lib.sip_lqr_solve_multi_workspace_bytes(self._plan, num_rhs)
+        if getattr(self, "_col_ws", None) is None or self._col_ws.numel() < need:
+            self._col_ws = torch.empty(max(1, need), dtype=torch.uint8, device=self.device)
+        _check(self._lib.sip_lqr_solve_multi(
+            self._plan, self._ptr(mats, self.batch, s.mats_len, "mats"), ctypes.c_void_p(vecs_cols.data_ptr()),
+            ctypes.c_void_p(sol_cols.data_ptr()), num_rhs, self._ptr(gains, self.batch, s.gains_len, "gains"),
+            ctypes.c_void_p(self.workspace.data_ptr()), ctypes.c_void_p(self._col_ws.data_ptr()),
+            ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_solve_multi")
+        return sol_cols
+
     def close(self):
         if getattr(self, "_plan", None):
             self._lib.sip_lqr_plan_destroy(self._plan)

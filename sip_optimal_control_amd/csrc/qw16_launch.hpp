@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "../../include/sip_lqr_amd.h"
+#include "chain_mrhs.hpp"
 #include "chain_qw16.hpp"
 
 #ifdef SIP_LQR_STAMPS
@@ -23,12 +24,32 @@ namespace sipamd {
 typedef hipError_t (*launch_fs_t)(long batch, int T, const void *mats, const void *vecs, void *sol, void *gains,
                                   int32_t *status, void *ws, hipStream_t stream, int mode, void *gfac);
 
+// LQR::solve for `ncols` right-hand sides in one sweep (chain_mrhs.hpp); columns `col_stride` scalars apart
+typedef hipError_t (*launch_mrhs_t)(long batch, int T, const void *mats, const void *vecs_cols, void *sol_cols,
+                                    const void *gains, const void *ws, const void *gfac, void *cws,
+                                    const int32_t *status, int ncols, long col_stride, hipStream_t stream);
+constexpr int kMrhsColumns = 8; // columns one multi-rhs launch carries
+
 struct KernelEntry {
   int dtype, n, m;
   const char *name;
   int ws_slot; // scalars of workspace per node
   launch_fs_t launch_fs;
+  launch_mrhs_t launch_mrhs; // nullptr: this shape solves several right-hand sides column by column
 };
+
+template <int N, int M, bool WPACK>
+hipError_t launch_mrhs_qw16(long batch, int T, const void *mats, const void *vecs_cols, void *sol_cols,
+                            const void *gains, const void *ws, const void *gfac, void *cws, const int32_t *status,
+                            int ncols, long col_stride, hipStream_t stream) {
+  if (ncols < 1 || ncols > kMrhsColumns)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL((chain_solve_mrhs_qw16<N, M, WPACK, kMrhsColumns>), dim3((unsigned)((batch + 3) / 4)), dim3(64),
+                     0, stream, (const double *)mats, (const double *)vecs_cols, (double *)sol_cols,
+                     (const double *)gains, (const double *)ws, (const double *)gfac, (double *)cws,
+                     (const int *)status, batch, T, ncols, col_stride);
+  return hipGetLastError();
+}
 
 template <int N, int M, bool STAGED, bool WPACK>
 hipError_t launch_qw16(long batch, int T, const void *mats, const void *vecs, void *sol, void *gains,
@@ -66,3 +87,13 @@ SIP_QW16_DECLARE_SLICE(4) SIP_QW16_DECLARE_SLICE(5) SIP_QW16_DECLARE_SLICE(6) SI
 #define QW16_STAGED(N, M)                                                                                     \
   { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",staged>/f64",                                   \
     sipamd::StagedCfg<N, M, true>::WSN, &sipamd::launch_qw16<N, M, true, true> }
+// ... with the multi-right-hand-side solve kernel of chain_mrhs.hpp (the shapes of the reference's
+// Newton-KKT benchmark grid, where the theta Schur complement solves p columns per factorization)
+#define QW16_STAGED_MR(N, M)                                                                                  \
+  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",staged>/f64",                                   \
+    sipamd::StagedCfg<N, M, true>::WSN, &sipamd::launch_qw16<N, M, true, true>,                               \
+    &sipamd::launch_mrhs_qw16<N, M, true> }
+#define QW16_DIRECT_MR(N, M)                                                                                  \
+  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",direct>/f64",                                   \
+    sipamd::StagedCfg<N, M, false>::WSN, &sipamd::launch_qw16<N, M, false, false>,                            \
+    &sipamd::launch_mrhs_qw16<N, M, false> }

@@ -712,6 +712,7 @@ namespace {
 
 struct ThetaRegions {
   double *J, *KJ, *S, *rhs_sw, *sol_sw, *vecs_cols, *lsol_cols; // the last two: chain plans only
+  void *cws; // column workspace of sip_lqr_solve_multi (chain plans)
 };
 ThetaRegions theta_regions(const sip_kkt_plan *p, void *theta_work) {
   const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, B = (size_t)p->batch;
@@ -725,7 +726,8 @@ ThetaRegions theta_regions(const sip_kkt_plan *p, void *theta_work) {
   r.sol_sw = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt);
   const size_t cols = p->chain_kernels ? sizeof(double) * B * (size_t)p->in1_len * p->theta_dim : 0;
   r.vecs_cols = (double *)(w + cur), cur = align256(cur + cols);
-  r.lsol_cols = (double *)(w + cur);
+  r.lsol_cols = (double *)(w + cur), cur = align256(cur + cols);
+  r.cws = w + cur;
   return r;
 }
 
@@ -791,8 +793,9 @@ size_t sip_kkt_theta_work_bytes(const sip_kkt_plan *p) {
     return 0;
   const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, B = (size_t)p->batch, th = (size_t)p->theta_dim;
   const size_t cols = p->chain_kernels ? align256(sizeof(double) * B * (size_t)p->in1_len * th) : 0;
+  const size_t cws = p->chain_kernels ? align256(sip_lqr_solve_multi_workspace_bytes(p->chain, p->theta_dim)) : 0;
   return 2 * align256(sizeof(double) * B * skkt * th) + align256(sizeof(double) * B * th * th) +
-         2 * align256(sizeof(double) * B * skkt) + 2 * cols;
+         2 * align256(sizeof(double) * B * skkt) + 2 * cols + cws;
 }
 
 int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const double *d_theta, const double *d_w,
@@ -835,11 +838,11 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
                        th, colJ, colV);
     if ((e = hipGetLastError()) != hipSuccess)
       return report(e, "sip_kkt_factor_theta(rhs)");
-    for (int col = 0; col < th; ++col) {
-      rc = sip_lqr_solve(p->chain, r.in0, t.vecs_cols + col * colV, t.lsol_cols + col * colV, r.gain, r.lqr, s);
-      if (rc != SIP_LQR_OK)
-        return rc;
-    }
+    // all columns through one backward / forward sweep where the shape has the multi-rhs kernel
+    // (chain_mrhs.hpp: the GEMM form of helpers.cpp:521-665), column by column otherwise
+    rc = sip_lqr_solve_multi(p->chain, r.in0, t.vecs_cols, t.lsol_cols, th, r.gain, r.lqr, t.cws, s);
+    if (rc != SIP_LQR_OK)
+      return rc;
     hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
                        p->lds_chain_recover, s, p->ck, d_model, (const double *)t.J, r.inv,
                        (const double *)t.lsol_cols, t.KJ, (const int32_t *)d_status, (long)p->batch, th, colJ, colV,

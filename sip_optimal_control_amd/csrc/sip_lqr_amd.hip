@@ -28,6 +28,8 @@ struct sip_lqr_plan {
   // fused factor+solve launcher of a dedicated kernel; nullptr: the general
   // engine (tree_generic.hpp) runs factor then solve
   sipamd::launch_fs_t launch_fs;
+  // several right-hand sides per sweep (chain_mrhs.hpp); nullptr: column by column
+  sipamd::launch_mrhs_t launch_mrhs = nullptr;
   // General engine on the packed chain layout: serves shapes / dtypes without
   // a dedicated kernel and the split factor / solve entry points.  Tables are
   // laid out and uploaded at plan creation, so that the compute entry points
@@ -82,21 +84,21 @@ using sipamd::KernelEntry;
     sipamd::mf32::Layout<M>::WSN, &launch_mf32<M> }
 
 const KernelEntry kKernels[] = {
-    MF32(8), QW16_STAGED(12, 4), QW16_STAGED(4, 2), QW16_DIRECT(12, 4),
+    MF32(8), QW16_STAGED_MR(12, 4), QW16_STAGED_MR(4, 2), QW16_DIRECT(12, 4),
     QW16_DIRECT(4, 2),  QW16_DIRECT(1, 1), QW16_DIRECT(2, 1),
-    QW16_DIRECT(3, 2),  QW16_DIRECT(8, 3),
+    QW16_DIRECT(3, 2),  QW16_DIRECT_MR(8, 3),
     // the grid of the reference's benchmarks (lqr_benchmark.cpp:537-545,
     // newton_kkt_benchmark.cpp:264-273: n in {4, 6, 8}, m in {1, 2, 3, 4}; n = 16 has no
     // vector lane left and runs on the general engine) and n = 12 with fewer controls
-    QW16_STAGED(4, 4),  QW16_STAGED(6, 2),  QW16_STAGED(6, 4),  QW16_STAGED(8, 2),
-    QW16_STAGED(8, 4),  QW16_STAGED(12, 2), QW16_DIRECT(4, 1),  QW16_DIRECT(4, 3),
-    QW16_DIRECT(6, 1),  QW16_DIRECT(6, 3),  QW16_DIRECT(8, 1),  QW16_DIRECT(12, 1),
-    QW16_DIRECT(12, 3),
+    QW16_STAGED_MR(4, 4),  QW16_STAGED_MR(6, 2),  QW16_STAGED_MR(6, 4),  QW16_STAGED_MR(8, 2),
+    QW16_STAGED_MR(8, 4),  QW16_STAGED_MR(12, 2), QW16_DIRECT_MR(4, 1),  QW16_DIRECT_MR(4, 3),
+    QW16_DIRECT_MR(6, 1),  QW16_DIRECT_MR(6, 3),  QW16_DIRECT_MR(8, 1),  QW16_DIRECT_MR(12, 1),
+    QW16_DIRECT_MR(12, 3),
     // hosts for the embedding of larger shapes (n <= 15: one lane of the row carries the affine column)
     QW16_STAGED(8, 8),  QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(14, 8), QW16_DIRECT(15, 4),
     QW16_DIRECT(15, 8),
     // n = 16 (in the reference's benchmark grid): distributed-vector mode, see chain_qw16.hpp
-    QW16_DIRECT(16, 1), QW16_DIRECT(16, 2), QW16_DIRECT(16, 3), QW16_DIRECT(16, 4), QW16_DIRECT(16, 8),
+    QW16_DIRECT_MR(16, 1), QW16_DIRECT_MR(16, 2), QW16_DIRECT_MR(16, 3), QW16_DIRECT_MR(16, 4), QW16_DIRECT(16, 8),
 };
 
 // Every other shape n <= 16, m <= 8 (qw16_extra.hip, compiled in SIP_QW16_SLICES slices).
@@ -407,6 +409,7 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
                                                      : "tree_generic(chain layout)/f64");
   p->ws_slot = k ? k->ws_slot : 0;
   p->launch_fs = k ? k->launch_fs : nullptr;
+  p->launch_mrhs = (k != nullptr && !p->padded) ? k->launch_mrhs : nullptr;
   p->solve_only = k != nullptr && k->dtype == SIP_LQR_F64;
   const char *split = std::getenv("SIP_LQR_SPLIT");
   p->split_on_fused = p->launch_fs != nullptr && !(split && std::strcmp(split, "general") == 0);
@@ -665,6 +668,48 @@ int sip_lqr_solve(const sip_lqr_plan *plan, const void *d_mats, const void *d_ve
             ? plan->gen.launch_solve<float>(plan->batch, d_mats, d_vecs, d_workspace, d_gains, d_sol, st, s)
             : plan->gen.launch_solve<double>(plan->batch, d_mats, d_vecs, d_workspace, d_gains, d_sol, st, s);
   return report(e, "sip_lqr_solve");
+}
+
+size_t sip_lqr_solve_multi_workspace_bytes(const sip_lqr_plan *plan, int num_rhs) {
+  if (plan == nullptr || num_rhs < 1 || plan->launch_mrhs == nullptr || !plan->split_on_fused)
+    return 0; // column-by-column path: no extra state
+  const int cols = std::min(num_rhs, sipamd::kMrhsColumns);
+  return (size_t)plan->batch * (size_t)(plan->T + 1) * (size_t)cols * (size_t)(2 * plan->n + plan->m) * sizeof(double);
+}
+
+int sip_lqr_solve_multi(const sip_lqr_plan *plan, const void *d_mats, const void *d_vecs_cols, void *d_sol_cols,
+                        int num_rhs, void *d_gains, void *d_workspace, void *d_col_workspace, void *stream) {
+  if (plan == nullptr || num_rhs < 0 || !d_mats || !d_workspace || (plan->T > 0 && !d_gains) ||
+      (num_rhs > 0 && (!d_vecs_cols || !d_sol_cols)))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  const size_t col_bytes = sip_lqr_vecs_bytes(plan);
+  if (plan->launch_mrhs == nullptr || !plan->split_on_fused) { // no multi-rhs kernel for this shape
+    for (int col = 0; col < num_rhs; ++col) {
+      const int rc = sip_lqr_solve(plan, d_mats, (const char *)d_vecs_cols + (size_t)col * col_bytes,
+                                   (char *)d_sol_cols + (size_t)col * col_bytes, d_gains, d_workspace, stream);
+      if (rc != SIP_LQR_OK)
+        return rc;
+    }
+    return SIP_LQR_OK;
+  }
+  if (num_rhs > 0 && d_col_workspace == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (require_device(plan) != hipSuccess)
+    return report(hipErrorNoDevice, "sip_lqr_solve_multi");
+  sipamd::DeviceGuard on_device(plan->device);
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_lqr_solve_multi(hipSetDevice)");
+  const FusedSplit f = fused_split_layout(plan);
+  const char *w = (const char *)d_workspace;
+  const long stride = (long)(col_bytes / sizeof(double));
+  hipError_t e = hipSuccess;
+  for (int col0 = 0; col0 < num_rhs && e == hipSuccess; col0 += sipamd::kMrhsColumns) {
+    const int nc = std::min(sipamd::kMrhsColumns, num_rhs - col0);
+    e = plan->launch_mrhs(plan->batch, plan->T, d_mats, (const char *)d_vecs_cols + (size_t)col0 * col_bytes,
+                          (char *)d_sol_cols + (size_t)col0 * col_bytes, d_gains, d_workspace, w + f.gfac,
+                          d_col_workspace, (const int32_t *)(w + f.status), nc, stride, (hipStream_t)stream);
+  }
+  return report(e, "sip_lqr_solve_multi");
 }
 
 const char *sip_lqr_kernel_name(const sip_lqr_plan *plan) {

@@ -83,7 +83,7 @@ def test_shipped_kernels_are_hazard_free():
         if "qw16" not in open(path).read():
             continue
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), path,
-                              "chain_factor_solve_qw16"], capture_output=True, text=True)
+                              "chain_factor_solve_qw16", "chain_solve_mrhs_qw16"], capture_output=True, text=True)
         assert out.returncode == 0, path + "\n" + out.stdout[-2000:]
         checked += 1
     assert checked >= 1 + entry.QW16_SLICES
