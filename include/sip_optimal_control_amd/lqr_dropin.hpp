@@ -337,6 +337,37 @@ public:
   }
   LQR(LQR &&) = default;
 
+  // ---- additions of this adapter (the reference has neither devices nor kernels to choose) ----
+  // HIP device ordinal of the objects constructed afterwards (default: SIP_LQR_DROPIN_DEVICE of the
+  // environment, else 0) / of this object (before its first factor or solve).
+  static int &default_device() {
+    static int dev = [] {
+      const char *v = std::getenv("SIP_LQR_DROPIN_DEVICE");
+      return v != nullptr ? std::atoi(v) : 0;
+    }();
+    return dev;
+  }
+  void set_device(int ordinal) {
+    device_ordinal_ = ordinal;
+    gpu_.reset();
+    fast_.reset();
+  }
+  // Uniform chains (Topology::set_chain + Dimensions::set_uniform) with a fused kernel (n <= 16,
+  // m <= 8) on the fused fp64 kernels of the batched path (sip_lqr_factor / sip_lqr_solve, batch 1)
+  // instead of the general tree engine: about an order of magnitude less latency per call.  The price:
+  // of the public LQR::Workspace fields only K and k are filled -- W, V, G_factor, F_factor,
+  // sqrt_delta(_inv) and v (read by helpers.cpp:521-665, the multi-rhs solve) stay untouched -- so it
+  // is opt-in (also: SIP_LQR_DROPIN_FUSED=1 in the environment).  Other problems ignore the switch.
+  static bool &default_fused_chains() {
+    static bool on = [] {
+      const char *v = std::getenv("SIP_LQR_DROPIN_FUSED");
+      return v != nullptr && v[0] == '1';
+    }();
+    return on;
+  }
+  void set_fused_chains(bool on) { fused_chains_ = on; }
+  bool uses_fused_chain_kernel() { return fast_chain() != nullptr; }
+
   // Replaces compile_topology_data (lqr.cpp:563-631); fills the traversal
   // arrays of the caller's workspace (read by helpers.cpp:217-218, 521-665 and
   // tests/lqr_test.cpp:940-950) and (re)creates the device plan.
@@ -348,6 +379,7 @@ public:
         workspace_.preorder_nodes, workspace_.postorder_nodes, workspace_.node_marks);
     traversal_status_ = static_cast<FactorStatus>(st);
     gpu_.reset();
+    fast_.reset();
     return traversal_status_;
   }
 
@@ -355,6 +387,8 @@ public:
   FactorStatus factor_with_status() {
     if (traversal_status_ != FactorStatus::SUCCESS)
       return traversal_status_;
+    if (FastChain *f = fast_chain())
+      return fast_factor(*f);
     Device &d = device();
     gather_input(d);
     d.h2d(d.d_in, d.h_in);
@@ -369,6 +403,8 @@ public:
 
   // Replaces lqr.cpp:735-871; requires a preceding successful factor.
   void solve(Output &output) {
+    if (FastChain *f = fast_chain())
+      return fast_solve(*f, output);
     Device &d = device();
     gather_input(d);
     d.h2d(d.d_in, d.h_in);
@@ -435,14 +471,101 @@ private:
     }
   }
 
+  // Fused-kernel state of a uniform chain (batch 1, packed chain layout of sip_lqr_amd.h).
+  struct FastChain {
+    sip_lqr_plan *plan = nullptr;
+    int n = 0, m = 0, T = 0;
+    void *d_mats = nullptr, *d_vecs = nullptr, *d_sol = nullptr, *d_gains = nullptr, *d_ws = nullptr;
+    int32_t *d_status = nullptr;
+    std::vector<double> h_mats, h_vecs, h_sol, h_gains;
+    ~FastChain() {
+      for (void *p : {d_mats, d_vecs, d_sol, d_gains, d_ws, (void *)d_status})
+        if (p != nullptr)
+          (void)hipFree(p);
+      sip_lqr_plan_destroy(plan);
+    }
+  };
+  // non-null iff the switch is on and the problem is a uniform chain with a fused fp64 kernel
+  FastChain *fast_chain() {
+    if (!fused_chains_)
+      return nullptr;
+    if (fast_)
+      return fast_->plan != nullptr ? fast_.get() : nullptr;
+    fast_ = std::make_unique<FastChain>(); // plan == nullptr: "looked, not applicable"
+    const Topology &t = input_.topology;
+    const Dimensions &dims = input_.dimensions;
+    const int E = t.num_edges;
+    if (E < 1 || t.root != 0)
+      return nullptr;
+    const int n = dims.get_state_dim(0), m = dims.get_control_dim(0);
+    if (n < 1 || m < 1 || n > 16 || m > 8)
+      return nullptr;
+    for (int e = 0; e < E; ++e)
+      if (t.edge_parents[e] != e || t.edge_children[e] != e + 1 || dims.get_control_dim(e) != m ||
+          dims.get_state_dim(e + 1) != n)
+        return nullptr;
+    FastChain &f = *fast_;
+    f.n = n, f.m = m, f.T = E;
+    check_hip(hipSetDevice(device_ordinal_), "hipSetDevice");
+    check(sip_lqr_plan_create(SIP_LQR_F64, 1, E, n, m, device_ordinal_, &f.plan), "sip_lqr_plan_create");
+    f.h_mats.assign(sip_lqr_mats_len(f.plan), 0.0), f.h_vecs.assign(sip_lqr_vecs_len(f.plan), 0.0);
+    f.h_sol.assign(sip_lqr_vecs_len(f.plan), 0.0), f.h_gains.assign(sip_lqr_gains_len(f.plan), 0.0);
+    auto alloc = [](void *&p, size_t bytes) { check_hip(hipMalloc(&p, std::max<size_t>(16, bytes)), "hipMalloc"); };
+    alloc(f.d_mats, sip_lqr_mats_bytes(f.plan)), alloc(f.d_vecs, sip_lqr_vecs_bytes(f.plan));
+    alloc(f.d_sol, sip_lqr_sol_bytes(f.plan)), alloc(f.d_gains, sip_lqr_gains_bytes(f.plan));
+    alloc(f.d_ws, sip_lqr_workspace_bytes(f.plan));
+    check_hip(hipMalloc((void **)&f.d_status, sizeof(int32_t)), "hipMalloc");
+    return &f;
+  }
+  // null tables (not yet patched by the caller, helpers.cpp:362-367 / 814-816) are passed as zeros
+  void fast_pack(FastChain &f) {
+    const int N = f.T + 1;
+    std::vector<double> zero((size_t)std::max(f.n * f.n, f.n * f.m) + 1, 0.0);
+    auto table = [&](double *const *tab, int count) {
+      std::vector<double *> out((size_t)count);
+      for (int i = 0; i < count; ++i)
+        out[i] = (tab != nullptr && tab[i] != nullptr) ? tab[i] : zero.data();
+      return out;
+    };
+    auto Q = table(input_.Q, N), q = table(input_.q, N), c = table(input_.c, N), dl = table(input_.delta, N);
+    auto Mx = table(input_.M, f.T), R = table(input_.R, f.T), r = table(input_.r, f.T), A = table(input_.A, f.T),
+         B = table(input_.B, f.T);
+    check(sip_lqr_pack_problem(f.plan, 0, Q.data(), Mx.data(), R.data(), q.data(), r.data(), A.data(), B.data(),
+                               c.data(), dl.data(), f.h_mats.data(), f.h_vecs.data()),
+          "sip_lqr_pack_problem");
+  }
+  FactorStatus fast_factor(FastChain &f) {
+    fast_pack(f);
+    check_hip(hipMemcpy(f.d_mats, f.h_mats.data(), f.h_mats.size() * sizeof(double), hipMemcpyHostToDevice), "H2D");
+    check(sip_lqr_factor(f.plan, f.d_mats, f.d_gains, f.d_status, f.d_ws, nullptr), "sip_lqr_factor");
+    int32_t st = 0;
+    check_hip(hipMemcpy(&st, f.d_status, sizeof(st), hipMemcpyDeviceToHost), "status copy");
+    fast_gains(f);
+    return static_cast<FactorStatus>(st);
+  }
+  void fast_gains(FastChain &f) { // K (after factor) and k (after solve) into the caller's workspace
+    check_hip(hipMemcpy(f.h_gains.data(), f.d_gains, f.h_gains.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+    if (workspace_.K != nullptr && workspace_.k != nullptr)
+      check(sip_lqr_unpack_gains(f.plan, 0, f.h_gains.data(), workspace_.K, workspace_.k), "sip_lqr_unpack_gains");
+  }
+  void fast_solve(FastChain &f, Output &output) {
+    fast_pack(f); // mats too: the caller may have re-patched the tables since factor (same values then)
+    check_hip(hipMemcpy(f.d_vecs, f.h_vecs.data(), f.h_vecs.size() * sizeof(double), hipMemcpyHostToDevice), "H2D");
+    check(sip_lqr_solve(f.plan, f.d_mats, f.d_vecs, f.d_sol, f.d_gains, f.d_ws, nullptr), "sip_lqr_solve");
+    check_hip(hipMemcpy(f.h_sol.data(), f.d_sol, f.h_sol.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+    check(sip_lqr_unpack_solution(f.plan, 0, f.h_sol.data(), output.x, output.u, output.y), "sip_lqr_unpack_solution");
+    fast_gains(f);
+  }
+
   Device &device() {
     if (gpu_)
       return *gpu_;
     auto d = std::make_unique<Device>();
     const Topology &t = input_.topology;
     const Dimensions &dims = input_.dimensions;
+    check_hip(hipSetDevice(device_ordinal_), "hipSetDevice"); // the arenas below live on the plan's device
     check(sip_lqr_tree_plan_create(1, t.num_edges, t.root, t.edge_parents, t.edge_children, dims.state_dims,
-                                   dims.control_dims, /*device=*/0, &d->plan),
+                                   dims.control_dims, device_ordinal_, &d->plan),
           "sip_lqr_tree_plan_create");
     d->max_n = dims.max_state_dim(t.num_nodes());
     d->h_in.assign(sip_lqr_tree_input_len(d->plan), 0.0);
@@ -523,6 +646,9 @@ private:
   Workspace &workspace_;
   FactorStatus traversal_status_;
   std::unique_ptr<Device> gpu_;
+  std::unique_ptr<FastChain> fast_;
+  int device_ordinal_ = default_device();
+  bool fused_chains_ = default_fused_chains();
 };
 
 } // namespace sip::optimal_control

@@ -553,6 +553,51 @@ int main() {
          }
          ws.free(3);
        }},
+      {"LQR.FusedChainSwitch (adapter addition: uniform chains on the fused kernels, explicit device)", [] {
+         // the reference's chain fixture (lqr_test.cpp:229-247) through sip_lqr_factor / sip_lqr_solve:
+         // same statuses, same solution (KKT residual < 1e-12), K and k in the caller's workspace
+         // satisfy u = K x + k (lqr.cpp:856-857); trees ignore the switch
+         auto p = nonuniform_diagonal_delta();
+         auto input = p.input();
+         LQR::Workspace ws;
+         ws.reserve(3, 2, 3);
+         {
+           auto lqr = LQR(input, ws);
+           lqr.set_device(0);
+           lqr.set_fused_chains(true);
+           CHECK(lqr.uses_fused_chain_kernel());
+           CHECK(lqr.factor_with_status() == Status::SUCCESS);
+           Solution s(p);
+           auto out = s.output();
+           lqr.solve(out);
+           lqr.solve(out); // repeatable (lqr_test.cpp:431-450)
+           CHECK(kkt_residual(p, s) < 1e-12);
+           double worst = 0.0;
+           for (int e = 0; e < 3; ++e)
+             for (int j = 0; j < 2; ++j) {
+               double pred = ws.k[e][j];
+               for (int col = 0; col < 3; ++col)
+                 pred += ws.K[e][j + 2 * col] * s.x[e][col];
+               worst = std::fmax(worst, std::fabs(pred - s.u[e][j]));
+             }
+           CHECK(worst < 1e-12);
+           p.delta[2][0] = 0.0;
+           CHECK(lqr.factor_with_status() == Status::INVALID_DELTA);
+           p.delta[2][0] = 0.3;
+         }
+         ws.free(3);
+         auto tree = branch_tree();
+         auto tin = tree.input();
+         LQR::Workspace tws;
+         tws.reserve(2, 1, 2);
+         {
+           auto lqr = LQR(tin, tws);
+           lqr.set_fused_chains(true);
+           CHECK(!lqr.uses_fused_chain_kernel());
+           CHECK(lqr.factor());
+         }
+         tws.free(2);
+       }},
   };
   for (auto &c : cases) {
     const int before = g_failures;

@@ -19,7 +19,7 @@ def test_cpp_dropin_suite():
     print(proc.stderr)
     assert proc.returncode == 0, proc.stdout[-3000:]
     assert "0 failures" in proc.stdout
-    assert proc.stdout.count("[  OK  ]") >= 17
+    assert proc.stdout.count("[  OK  ]") >= 18
 
 
 def test_cpp_callback_provider_suite():

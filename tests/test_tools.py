@@ -87,3 +87,17 @@ def test_shipped_kernels_are_hazard_free():
         assert out.returncode == 0, path + "\n" + out.stdout[-2000:]
         checked += 1
     assert checked >= 1 + entry.QW16_SLICES
+    # The staged kernels conclude from counted `s_waitcnt vmcnt(N)` that their LDS-DMA has landed
+    # (chain_qw16.hpp); a register spill would add scratch loads / stores to that count.
+    import re
+    staged = 0
+    for path in listings:
+        text = open(path).read()
+        for m in re.finditer(r"\.amdhsa_kernel (\S*chain_factor_solve_qw16\S*)(.*?)\.end_amdhsa_kernel", text, re.S):
+            body = text[text.index(m.group(1) + ":"):]
+            body = body[:body.index("s_endpgm")]
+            if "global_load_lds" not in body:
+                continue
+            staged += 1
+            assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", m.group(2)), m.group(1) + " uses scratch"
+    assert staged >= 10
