@@ -266,6 +266,20 @@ int sip_lqr_tree_solve(const sip_lqr_tree_plan *plan, const double *d_input,
                        double *d_work, double *d_output,
                        const int32_t *d_status, void *stream);
 
+/* Replaces: factor_with_status() + solve() (the loop body of BM_LQRVariableFactorSolve,
+ * benchmarks/lqr_benchmark.cpp:716-744) for every instance, as one fused sweep: trees whose state
+ * dimensions are <= 15 and control dimensions <= 8 run on a padded size class of the
+ * broadcast-FMA kernels (csrc/tree_qw16.hpp; sip_lqr_tree_kernel_name() tells), anything else on the
+ * general engine (factor, then solve).  Fills d_output (x, y, u), d_status and, of d_work, the
+ * K and k fields of every edge (d_work may be NULL on the fused path: no gains wanted); the other
+ * LQR::Workspace fields of d_work are only filled by sip_lqr_tree_factor().  d_scratch:
+ * sip_lqr_tree_fused_scratch_bytes() bytes of device scratch (0: general engine, may be NULL). */
+size_t sip_lqr_tree_fused_scratch_bytes(const sip_lqr_tree_plan *plan);
+int sip_lqr_tree_factor_solve(const sip_lqr_tree_plan *plan, const double *d_input,
+                              double *d_work, double *d_output, int32_t *d_status,
+                              void *d_scratch, void *stream);
+const char *sip_lqr_tree_kernel_name(const sip_lqr_tree_plan *plan);
+
 /* Name of the kernel variant the plan dispatches to (static string). */
 const char *sip_lqr_kernel_name(const sip_lqr_plan *plan);
 

@@ -6,16 +6,24 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 
 #include "generic_plan.hpp"
+#include "tree_qw16_launch.hpp"
 
 struct sip_lqr_tree_plan {
   int64_t batch = 0;
   int device = 0;
   int topology_status = SIP_LQR_INVALID_TOPOLOGY;
   sipamd::GenericPlan g;
+  // fused factor + solve on the padded size class (tree_qw16.hpp); nullptr: general engine only
+  const sipamd::TreeClass *fused = nullptr;
+  sipamd::TreeTopo topo{};
+  sipamd::TreeNative native{};
+  size_t at_spill = 0, scratch_bytes = 0; // scratch: padded gains at 0, then the spill
 };
 
 extern "C" {
@@ -113,6 +121,25 @@ int sip_lqr_tree_plan_create(int64_t batch, int num_edges, int root,
     *out = nullptr;
     return SIP_LQR_ERR_HIP;
   }
+  // fused path: a padded size class of the broadcast-FMA tree kernel, when the tree fits one
+  const char *variant = std::getenv("SIP_LQR_TREE");
+  const bool general_only = variant != nullptr && (std::strcmp(variant, "general") == 0 || std::strcmp(variant, "global") == 0);
+  p->fused = general_only ? nullptr : sipamd::find_tree_class(std::max(1, g.max_n), std::max(1, g.max_m));
+  if (p->fused != nullptr) {
+    const sipamd::tree::Meta &m = g.meta;
+    p->topo = sipamd::TreeTopo{E, N, root, m.edge_parents, m.edge_children, m.child_offsets, m.child_edges,
+                               m.preorder, m.postorder};
+    sipamd::TreeNative &t = p->native;
+    t.sd = m.state_dims, t.cd = m.control_dims;
+    t.oQ = m.oQ, t.oq = m.oq, t.oc = m.oc, t.od = m.od, t.oA = m.oA, t.oB = m.oB, t.oM = m.oM, t.oR = m.oR;
+    t.orr = m.orr, t.ox = m.ox, t.oy = m.oy, t.ou = m.ou, t.oK = m.oK, t.ok = m.ok;
+    t.in_len = g.in0_len, t.out_len = g.out_len, t.ws_len = g.ws_len;
+    const size_t PN = p->fused->n, PM = p->fused->m, B = (size_t)batch * sizeof(double);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t cur = up(B * ((size_t)E * (PM * PN + PM))); // padded gains at 0
+    p->at_spill = cur, cur = up(cur + B * ((size_t)N * (PN * PN + 4 * PN)));
+    p->scratch_bytes = cur;
+  }
   return SIP_LQR_OK;
 }
 
@@ -188,6 +215,43 @@ int sip_lqr_tree_solve(const sip_lqr_tree_plan *plan, const double *d_input,
                                                     d_output, d_status, (hipStream_t)stream);
   if (e != hipSuccess) {
     std::fprintf(stderr, "sip_lqr_tree_solve: %s\n", hipGetErrorString(e));
+    return SIP_LQR_ERR_HIP;
+  }
+  return SIP_LQR_OK;
+}
+
+
+const char *sip_lqr_tree_kernel_name(const sip_lqr_tree_plan *plan) {
+  if (plan == nullptr)
+    return "";
+  return plan->fused != nullptr ? plan->fused->name : "tree_generic/f64";
+}
+
+size_t sip_lqr_tree_fused_scratch_bytes(const sip_lqr_tree_plan *plan) {
+  return (plan != nullptr && plan->fused != nullptr) ? plan->scratch_bytes : 0;
+}
+
+int sip_lqr_tree_factor_solve(const sip_lqr_tree_plan *plan, const double *d_input, double *d_work, double *d_output,
+                              int32_t *d_status, void *d_scratch, void *stream) {
+  if (plan == nullptr || d_status == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (plan->topology_status != SIP_LQR_SUCCESS || plan->fused == nullptr) { // general engine, two launches
+    const int rc = sip_lqr_tree_factor(plan, d_input, d_work, d_status, stream);
+    if (rc != SIP_LQR_OK || plan->topology_status != SIP_LQR_SUCCESS)
+      return rc;
+    return sip_lqr_tree_solve(plan, d_input, d_work, d_output, d_status, stream);
+  }
+  if ((d_input == nullptr && plan->g.in0_len > 0) || (d_output == nullptr && plan->g.out_len > 0) || d_scratch == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  sipamd::DeviceGuard on_device(plan->device);
+  if (on_device.err != hipSuccess)
+    return SIP_LQR_ERR_HIP;
+  hipStream_t s = (hipStream_t)stream;
+  char *w = (char *)d_scratch;
+  const hipError_t e = plan->fused->launch(plan->topo, plan->native, d_input, d_output, d_work, (double *)w,
+                                           (double *)(w + plan->at_spill), d_status, (long)plan->batch, s);
+  if (e != hipSuccess) {
+    std::fprintf(stderr, "sip_lqr_tree_factor_solve: %s\n", hipGetErrorString(e));
     return SIP_LQR_ERR_HIP;
   }
   return SIP_LQR_OK;

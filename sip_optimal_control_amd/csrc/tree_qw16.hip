@@ -1,0 +1,29 @@
+// tree_qw16.hip -- size classes of the fused tree kernel (tree_qw16.hpp) and their launcher; its
+// own translation unit so that it compiles beside the others.
+#include "tree_qw16_launch.hpp"
+
+namespace sipamd {
+
+namespace {
+template <int N, int M>
+hipError_t launch(const TreeTopo &tp, const TreeNative &tn, const double *input, double *output, double *work,
+                  double *pgains, double *spill, int32_t *status, long batch, hipStream_t s) {
+  hipLaunchKernelGGL((tree_factor_solve_qw16<N, M>), dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, s, tp, tn, input,
+                     output, work, pgains, spill, (int *)status, batch);
+  return hipGetLastError();
+}
+#define TREE_CLASS(N, M) {N, M, "tree_factor_solve_qw16<" #N "," #M ">/f64", &launch<N, M>}
+// sorted by cost: the first class that holds the largest node and the largest control wins
+const TreeClass kClasses[] = {TREE_CLASS(4, 2),  TREE_CLASS(6, 3),  TREE_CLASS(8, 4),  TREE_CLASS(10, 4),
+                              TREE_CLASS(12, 4), TREE_CLASS(15, 4), TREE_CLASS(15, 8)};
+#undef TREE_CLASS
+} // namespace
+
+const TreeClass *find_tree_class(int max_n, int max_m) {
+  for (const TreeClass &k : kClasses)
+    if (k.n >= max_n && k.m >= max_m)
+      return &k;
+  return nullptr;
+}
+
+} // namespace sipamd

@@ -180,3 +180,136 @@ def test_reference_variable_benchmark_shapes(oracle_lib, shape, T, base_n):
             np.testing.assert_allclose(a, bb, rtol=0, atol=1e-10 * max(1.0, np.abs(bb).max()))
         assert dense_kkt.residual_norm(prob["parents"], prob["children"], prob["state_dims"], prob["control_dims"],
                                        prob["blocks"], x, u, y) < 1e-9
+
+
+# ---- the fused size-class path (csrc/tree_qw16.hpp) through sip_lqr_tree_factor_solve -------------------
+def _check_against_oracle(oracle_lib, s, probs, tol=1e-10, expect=None):
+    out, st = s.factor_solve()
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    for b, blocks in enumerate(probs):
+        lqr = oracle_lib.TreeLQR(s.parents, s.children, s.state_dims, s.control_dims, blocks)
+        ref = lqr.factor()
+        assert ref == st[b], (b, ref, st[b])
+        if expect is not None:
+            assert ref == expect[b]
+        if ref != 0:
+            continue
+        xo, uo, yo = lqr.solve()
+        x, u, y = s.unpack_solution(b)
+        for a, bb in list(zip(x, xo)) + list(zip(u, uo)) + list(zip(y, yo)):
+            np.testing.assert_allclose(a, bb, rtol=0, atol=tol * max(1.0, np.abs(bb).max(initial=0.0)))
+        Ko, ko = lqr.gains()
+        Kg, kg = s.unpack_gains(b)
+        for a, bb in list(zip(Kg, Ko)) + list(zip(kg, ko)):
+            np.testing.assert_allclose(a, bb, rtol=0, atol=tol * max(1.0, np.abs(bb).max(initial=0.0)))
+
+
+@pytest.mark.parametrize("name", ["nonuniform_diagonal_delta", "branch_tree", "variable_dimension_branch",
+                                  "five_node_variable_tree_eigen", "default_chain"])
+def test_fused_tree_kernel_on_the_reference_fixtures(oracle_lib, name):
+    """tests/lqr_test.cpp:229-263, 411-429, 641-659, 982-1013 through the fused sweep: residual < 1e-12,
+    x, u, y and K, k against the oracle; twice on the same object (lqr_test.cpp:431-450)."""
+    prob = rp.default_chain(2, 1, 2) if name == "default_chain" else getattr(rp, name)()
+    s = _solver(prob)
+    assert "tree_factor_solve_qw16" in s.kernel_name
+    s.pack([prob["blocks"]])
+    for _ in range(2):
+        _check_against_oracle(oracle_lib, s, [prob["blocks"]], tol=1e-12)
+    x, u, y = s.unpack_solution()
+    assert dense_kkt.residual_norm(prob["parents"], prob["children"], prob["state_dims"], prob["control_dims"],
+                                   prob["blocks"], x, u, y) < 1e-12
+
+
+def test_fused_tree_kernel_statuses_and_precedence(oracle_lib):
+    """FactorStatus through the fused sweep (lqr.hpp:68-74): the KATs of lqr_test.cpp:188-227 and, on a
+    five-node tree, first failing node in postorder and G before delta before F at a node
+    (lqr.cpp:696-701, 722-727)."""
+    def status_of(prob):
+        s = _solver(prob)
+        s.pack([prob["blocks"]])
+        _, st = s.factor_solve()
+        torch.cuda.synchronize()
+        lqr = oracle_lib.TreeLQR(prob["parents"], prob["children"], prob["state_dims"], prob["control_dims"],
+                                 prob["blocks"])
+        assert lqr.factor() == int(st[0])
+        return int(st[0])
+    assert status_of(rp.default_chain(2, 1, 2)) == 0
+    p = rp.default_chain(2, 1, 2); p["blocks"]["delta"][2][0] = 0.0
+    assert status_of(p) == 1
+    p = rp.default_chain(1, 1, 1); p["blocks"]["Q"][1][0, 0] = -2.0
+    assert status_of(p) == 2
+    p = rp.default_chain(1, 1, 1); p["blocks"]["Q"][1][0, 0] = 0.0; p["blocks"]["R"][0][0, 0] = -1.0
+    assert status_of(p) == 3
+    # five-node tree: parents {0,0,1,1}, children {1,2,3,4}; postorder 2, 4, 3, 1, 0
+    base = rp.five_node_variable_tree_eigen
+    p = base(); p["blocks"]["R"][2] = -1e4 * np.eye(p["control_dims"][2]); p["blocks"]["delta"][1][0] = 0.0
+    assert status_of(p) == 3      # node 1: its child edge 2 (G) before its own delta
+    p = base(); p["blocks"]["delta"][1][0] = 0.0; p["blocks"]["Q"][1] = -1e6 * np.eye(p["state_dims"][1])
+    assert status_of(p) == 1      # same node: delta before F
+    p = base(); p["blocks"]["delta"][4][0] = -1.0; p["blocks"]["R"][0] = -1e4 * np.eye(p["control_dims"][0])
+    assert status_of(p) == 1      # node 4 precedes edge 0 (processed at the root) in postorder
+    p = base(); p["blocks"]["Q"][2] = -1e6 * np.eye(p["state_dims"][2]); p["blocks"]["delta"][3][0] = 0.0
+    assert status_of(p) == 2      # node 2 is first in postorder
+
+
+def test_fused_tree_kernel_random_batches(oracle_lib):
+    """Random trees with per-node dimensions in several size classes, zero-dimensional nodes, one
+    failing instance per batch, a batch that is not a multiple of the 4 problems of a wavefront."""
+    rng = np.random.default_rng(77)
+    for trial, (nmax, mmax, N) in enumerate([(4, 2, 7), (6, 3, 12), (9, 4, 9), (12, 4, 6), (15, 3, 5), (14, 8, 4)]):
+        parents = [int(rng.integers(0, e + 1)) for e in range(N - 1)]
+        children = list(range(1, N))
+        sd = [int(rng.integers(0 if trial % 2 else 1, nmax + 1)) for _ in range(N)]
+        sd[int(rng.integers(0, N))] = nmax
+        cd = [int(rng.integers(1, mmax + 1)) for _ in range(N - 1)]
+        cd[0] = mmax
+        batch = 6
+        probs = []
+        for b in range(batch):
+            blocks = {k: [] for k in ("Q", "M", "R", "q", "r", "A", "B", "c", "delta")}
+            for n in sd:
+                S = rng.normal(size=(n, n))
+                blocks["Q"].append(S.T @ S + 1e-3 * np.eye(n))
+                blocks["q"].append(rng.normal(size=n)); blocks["c"].append(rng.normal(size=n))
+                blocks["delta"].append(1e-3 + 0.1 * rng.random(n))
+            for e, m in enumerate(cd):
+                np_, nc = sd[parents[e]], sd[children[e]]
+                G = rng.normal(size=(m, m))
+                blocks["A"].append(0.3 * rng.normal(size=(nc, np_))); blocks["B"].append(0.3 * rng.normal(size=(nc, m)))
+                blocks["M"].append(0.05 * rng.normal(size=(np_, m))); blocks["R"].append(G.T @ G + 1.01 * np.eye(m))
+                blocks["r"].append(rng.normal(size=m))
+            probs.append(blocks)
+        probs[3]["R"][N - 2] = -1e4 * np.eye(cd[N - 2])
+        s = _solver(dict(parents=parents, children=children, state_dims=sd, control_dims=cd), batch=batch)
+        assert "tree_factor_solve_qw16" in s.kernel_name, s.kernel_name
+        s.pack(probs)
+        _check_against_oracle(oracle_lib, s, probs, tol=1e-10, expect=[0, 0, 0, 3, 0, 0])
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])
+@pytest.mark.parametrize("T,base_n", [(31, 4), (63, 8)])
+def test_fused_tree_kernel_on_the_variable_benchmark_family(oracle_lib, shape, T, base_n):
+    """BM_LQRVariableFactorSolve (benchmarks/lqr_benchmark.cpp:209-310, 716-744): heterogeneous chain,
+    shallow wide tree (63 edges out of the root), binary tree; and the general engine agrees."""
+    rng = np.random.default_rng(17 + 31 * shape)
+    batch = 5
+    probs = [rp.variable_benchmark_problem(shape, T, base_n, 2, rng) for _ in range(batch)]
+    s = _solver(probs[0], batch=batch)
+    assert "tree_factor_solve_qw16" in s.kernel_name
+    s.pack([p["blocks"] for p in probs])
+    _check_against_oracle(oracle_lib, s, [p["blocks"] for p in probs], tol=1e-10)
+    fused = s.output.clone()
+    s.factor(); s.solve()
+    torch.cuda.synchronize()
+    assert float((s.output - fused).abs().max()) <= 1e-10 * float(fused.abs().max())
+
+
+def test_trees_beyond_the_size_classes_fall_back_to_the_general_engine(oracle_lib, monkeypatch):
+    prob = rp.default_chain(17, 2, 3)
+    s = _solver(prob)
+    assert s.kernel_name == "tree_generic/f64"
+    s.pack([prob["blocks"]])
+    _check_against_oracle(oracle_lib, s, [prob["blocks"]], tol=1e-10)
+    monkeypatch.setenv("SIP_LQR_TREE", "general")
+    assert _solver(rp.branch_tree()).kernel_name == "tree_generic/f64"

@@ -73,20 +73,20 @@ def test_shipped_kernels_are_hazard_free():
     import __graft_entry__ as entry
     pattern = os.path.join(ROOT, "build", "obj", "*", "*-hip-amdgcn-amd-amdhsa-gfx950.s")
     entry.build_hip()
-    if len(glob.glob(pattern)) < 3 + entry.QW16_SLICES or not entry.listings_current():
+    if len(glob.glob(pattern)) < 4 + entry.QW16_SLICES or not entry.listings_current():
         entry.build_hip(force=True)  # library from elsewhere (no build/obj): rebuild with listings
     listings = sorted(glob.glob(pattern))
     units = {os.path.basename(os.path.dirname(p)) for p in listings}
-    assert {"sip_lqr_amd"} | {"qw16_extra_%d" % k for k in range(entry.QW16_SLICES)} <= units
+    assert {"sip_lqr_amd", "tree_qw16"} | {"qw16_extra_%d" % k for k in range(entry.QW16_SLICES)} <= units
     checked = 0
     for path in listings:
         if "qw16" not in open(path).read():
             continue
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), path,
-                              "chain_factor_solve_qw16", "chain_solve_mrhs_qw16"], capture_output=True, text=True)
+                              "chain_factor_solve_qw16", "chain_solve_mrhs_qw16", "tree_factor_solve_qw16"], capture_output=True, text=True)
         assert out.returncode == 0, path + "\n" + out.stdout[-2000:]
         checked += 1
-    assert checked >= 1 + entry.QW16_SLICES
+    assert checked >= 2 + entry.QW16_SLICES
     # The staged kernels conclude from counted `s_waitcnt vmcnt(N)` that their LDS-DMA has landed
     # (chain_qw16.hpp); a register spill would add scratch loads / stores to that count.
     import re
