@@ -21,9 +21,13 @@ struct sip_lqr_tree_plan {
   sipamd::GenericPlan g;
   // fused factor + solve on the padded size class (tree_qw16.hpp); nullptr: general engine only
   const sipamd::TreeClass *fused = nullptr;
-  sipamd::TreeTopo topo{};
-  sipamd::TreeNative native{};
+  sipamd::TreeSchedule sched{};
+  void *d_steps = nullptr;
   size_t at_spill = 0, scratch_bytes = 0; // scratch: padded gains at 0, then the spill
+  ~sip_lqr_tree_plan() {
+    if (d_steps != nullptr)
+      (void)hipFree(d_steps);
+  }
 };
 
 extern "C" {
@@ -124,15 +128,76 @@ int sip_lqr_tree_plan_create(int64_t batch, int num_edges, int root,
   // fused path: a padded size class of the broadcast-FMA tree kernel, when the tree fits one
   const char *variant = std::getenv("SIP_LQR_TREE");
   const bool general_only = variant != nullptr && (std::strcmp(variant, "general") == 0 || std::strcmp(variant, "global") == 0);
-  p->fused = general_only ? nullptr : sipamd::find_tree_class(std::max(1, g.max_n), std::max(1, g.max_m));
+  // (its clamped loads need one readable scalar in the input and the output arena)
+  p->fused = (general_only || g.in0_len < 1 || g.out_len < 1)
+                 ? nullptr
+                 : sipamd::find_tree_class(std::max(1, g.max_n), std::max(1, g.max_m));
   if (p->fused != nullptr) {
-    const sipamd::tree::Meta &m = g.meta;
-    p->topo = sipamd::TreeTopo{E, N, root, m.edge_parents, m.edge_children, m.child_offsets, m.child_edges,
-                               m.preorder, m.postorder};
-    sipamd::TreeNative &t = p->native;
-    t.sd = m.state_dims, t.cd = m.control_dims;
-    t.oQ = m.oQ, t.oq = m.oq, t.oc = m.oc, t.od = m.od, t.oA = m.oA, t.oB = m.oB, t.oM = m.oM, t.oR = m.oR;
-    t.orr = m.orr, t.ox = m.ox, t.oy = m.oy, t.ou = m.ou, t.oK = m.oK, t.ok = m.ok;
+    // the flattened traversal (TreeStep records, tree_qw16.hpp), from the host copies of the tables
+    std::vector<sipamd::TreeStep> steps;
+    auto node_fields = [&](sipamd::TreeStep &st, int j) {
+      st.node = j, st.n = g.state_dims[j];
+      st.oQ = g.oQ[j], st.oq = g.oq[j], st.oc = g.oc[j], st.od = g.od[j];
+    };
+    auto edge_fields = [&](sipamd::TreeStep &st, int e) {
+      const int ch = g.children[e];
+      st.edge = e, st.child = ch, st.nc = g.state_dims[ch], st.m = g.control_dims[e];
+      st.oA = g.oA[e], st.oB = g.oB[e], st.oM = g.oM[e], st.oR = g.oR[e], st.orr = g.orr[e], st.odc = g.od[ch];
+      st.oK = g.oK[e], st.ok = g.ok[e], st.ou = g.ou[e], st.oxc = g.ox[ch], st.oyc = g.oy[ch];
+      st.oxp = g.ox[g.parents[e]];
+    };
+    int finished = -1; // node finished by the previous backward step
+    for (int idx = 0; idx < N; ++idx) {
+      const int j = g.postorder[idx];
+      const int lo = g.child_offsets[j], hi = g.child_offsets[j + 1];
+      for (int ci = lo; ci < hi; ++ci) {
+        sipamd::TreeStep st{};
+        st.kind = 0;
+        node_fields(st, j);
+        edge_fields(st, g.child_edges[ci]);
+        st.flags = (ci == lo ? sipamd::TS_LOAD_V : 0) | (st.child == finished ? sipamd::TS_CHILD_LIVE : 0);
+        steps.push_back(st);
+        finished = -1;
+      }
+      sipamd::TreeStep st{};
+      st.kind = 1;
+      node_fields(st, j);
+      st.flags = lo == hi ? sipamd::TS_LOAD_V : 0;
+      steps.push_back(st);
+      finished = j;
+    }
+    const size_t n_backward = steps.size();
+    int produced = root; // node whose x the previous forward step produced (the root's comes first)
+    for (int idx = 0; idx < N; ++idx) {
+      const int j = g.preorder[idx];
+      for (int ci = g.child_offsets[j]; ci < g.child_offsets[j + 1]; ++ci) {
+        sipamd::TreeStep st{};
+        node_fields(st, j);
+        edge_fields(st, g.child_edges[ci]);
+        st.flags = j == produced ? sipamd::TS_CHILD_LIVE : 0;
+        steps.push_back(st);
+        produced = st.child;
+      }
+    }
+    {
+      sipamd::DeviceGuard on_device(device);
+      hipError_t he = on_device.err;
+      if (he == hipSuccess)
+        he = hipMalloc(&p->d_steps, std::max<size_t>(1, steps.size()) * sizeof(sipamd::TreeStep));
+      if (he == hipSuccess)
+        he = hipMemcpy(p->d_steps, steps.data(), steps.size() * sizeof(sipamd::TreeStep), hipMemcpyHostToDevice);
+      if (he != hipSuccess) {
+        std::fprintf(stderr, "sip_lqr_tree_plan_create: HIP error: %s\n", hipGetErrorString(he));
+        delete p;
+        *out = nullptr;
+        return SIP_LQR_ERR_HIP;
+      }
+    }
+    sipamd::TreeSchedule &t = p->sched;
+    t.backward = (const sipamd::TreeStep *)p->d_steps, t.forward = t.backward + n_backward;
+    t.n_backward = (int)n_backward, t.n_forward = (int)(steps.size() - n_backward);
+    t.Nn = N, t.E = E, t.root = root, t.root_n = g.state_dims[root];
+    t.root_od = g.od[root], t.root_ox = g.ox[root], t.root_oy = g.oy[root];
     t.in_len = g.in0_len, t.out_len = g.out_len, t.ws_len = g.ws_len;
     const size_t PN = p->fused->n, PM = p->fused->m, B = (size_t)batch * sizeof(double);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -248,7 +313,7 @@ int sip_lqr_tree_factor_solve(const sip_lqr_tree_plan *plan, const double *d_inp
     return SIP_LQR_ERR_HIP;
   hipStream_t s = (hipStream_t)stream;
   char *w = (char *)d_scratch;
-  const hipError_t e = plan->fused->launch(plan->topo, plan->native, d_input, d_output, d_work, (double *)w,
+  const hipError_t e = plan->fused->launch(plan->sched, d_input, d_output, d_work, (double *)w,
                                            (double *)(w + plan->at_spill), d_status, (long)plan->batch, s);
   if (e != hipSuccess) {
     std::fprintf(stderr, "sip_lqr_tree_factor_solve: %s\n", hipGetErrorString(e));

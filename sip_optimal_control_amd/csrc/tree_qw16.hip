@@ -6,9 +6,9 @@ namespace sipamd {
 
 namespace {
 template <int N, int M>
-hipError_t launch(const TreeTopo &tp, const TreeNative &tn, const double *input, double *output, double *work,
-                  double *pgains, double *spill, int32_t *status, long batch, hipStream_t s) {
-  hipLaunchKernelGGL((tree_factor_solve_qw16<N, M>), dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, s, tp, tn, input,
+hipError_t launch(const TreeSchedule &ts, const double *input, double *output, double *work, double *pgains,
+                  double *spill, int32_t *status, long batch, hipStream_t s) {
+  hipLaunchKernelGGL((tree_factor_solve_qw16<N, M>), dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, s, ts, input,
                      output, work, pgains, spill, (int *)status, batch);
   return hipGetLastError();
 }

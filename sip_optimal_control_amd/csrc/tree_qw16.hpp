@@ -9,7 +9,8 @@
 // R = I, delta = 1 on their diagonal and zeros elsewhere decouple exactly: x = y = u = 0 there), so the
 // arithmetic is that of a uniform tree and no padded copy of the inputs or outputs ever exists.
 //
-// Traversal as the reference (lqr.cpp:645-731, 735-871): nodes in postorder, the child edges of a node
+// Traversal as the reference (lqr.cpp:645-731, 735-871), flattened on the host into one record per
+// step (TreeStep): nodes in postorder, the child edges of a node
 // in CSR order (so a failing factorization reports the status of the first failing node / edge, G
 // before delta before F at a node); rollout in preorder.  What a chain keeps in registers from one
 // stage to the next, a tree fetches from the per-node spill when the PARENT is processed:
@@ -17,7 +18,10 @@
 // W of a child is rebuilt from its S (W = D^{-1/2}(I - S)D^{-1/2}, lqr.cpp:521-528), the affine
 // column of [F | g] = W [A | t] + [0 | v] starts from the child's (t, v), and V of the parent
 // accumulates A^T F + K^T H over its child edges (lqr.cpp:715-719).  The rollout reads the parent's x
-// back from the solution arena.  Sibling subtrees are processed one after the other by the same
+// back from the solution arena.  The FIRST child of a node is always the node finished immediately
+// before it (postorder = reversed preorder), so its W, t, v are taken from registers instead (a chain
+// never reads its spill in the backward sweep), and likewise x of the parent in the rollout.  Sibling
+// subtrees are processed one after the other by the same
 // 16-lane row: with a batch that fills the machine (4 problems per wavefront) sibling parallelism
 // inside a problem has nothing left to fill.
 //
@@ -31,18 +35,35 @@
 
 namespace sipamd {
 
-struct TreeTopo { // device arrays of the compiled traversal (GenericPlan)
-  int E, Nn, root;
-  const int *parents, *children, *child_offsets, *child_edges, *preorder, *postorder;
+// One step of the flattened traversal (built on the host from the compiled topology, one table per
+// plan): everything a step needs is ONE record read by scalar loads, instead of a chain of dependent
+// table look-ups (postorder -> child_offsets -> child_edges -> children -> dims -> offsets) in front
+// of every step.  Offsets are in doubles from the start of one problem inside its tree-native arena
+// (include/sip_lqr_amd.h).
+//   backward: for node in postorder { EDGE step per child edge, in CSR order; then the NODE step }
+//   forward : one step per edge, parents in preorder, child edges in CSR order
+struct TreeStep {
+  int kind;   // backward: 0 = edge, 1 = node
+  int node;   // edge steps: the parent; node steps: the node
+  int edge, child;
+  int n, nc, m; // dim(node), dim(child), control dim of the edge
+  int flags;    // TS_*
+  long oQ, oq, oc, od;             // input arena, of `node`
+  long oA, oB, oM, oR, orr, odc;   // input arena, of the edge; delta of the child
+  long oK, ok;                     // work arena: K, k of the edge
+  long ou, oxc, oyc, oxp;          // output arena: u of the edge, x / y of the child, x of the parent
+};
+enum {
+  TS_LOAD_V = 1,    // backward: [V | v] = [Q | q] of `node` first (first child edge of a node / a leaf's node step)
+  TS_CHILD_LIVE = 2 // backward edge: the child was finished by the previous step: its W, t, v are still in registers
+                    // forward edge: x of the parent is the x the previous step produced (still in registers)
 };
 
-// Tree-native arenas of include/sip_lqr_amd.h (per-node / per-edge dimensions, offsets in doubles
-// from the start of one problem) as the kernel reads and writes them directly.
-struct TreeNative {
-  const int *sd, *cd;                                      // state dims per node, control dims per edge
-  const long *oQ, *oq, *oc, *od, *oA, *oB, *oM, *oR, *orr; // input arena
-  const long *ox, *oy, *ou;                                // output arena
-  const long *oK, *ok;                                     // work arena: K, k of every edge
+struct TreeSchedule { // device tables + sizes
+  const TreeStep *backward, *forward;
+  int n_backward, n_forward; // Nn + E, E
+  int Nn, E, root, root_n;
+  long root_od, root_ox, root_oy;
   long in_len, out_len, ws_len;
 };
 
@@ -54,7 +75,7 @@ struct TreeLayout {
 
 template <int N, int M>
 __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
-    const TreeTopo tp, const TreeNative tn, const double *__restrict__ in_all, double *__restrict__ out_all,
+    const TreeSchedule ts, const double *__restrict__ in_all, double *__restrict__ out_all,
     double *__restrict__ work_all /* may be null: K, k not wanted */, double *__restrict__ gains,
     double *__restrict__ wsp, int *__restrict__ status, const long batch) {
   static_assert(N >= 1 && N <= 15, "one lane of the row carries the affine column");
@@ -66,70 +87,103 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
   if (!valid)
     p = batch - 1;
   const bool isM = c < N, isV = c == N;
-  const int Nn = tp.Nn, E_ = tp.E;
-  const double *in = in_all + p * tn.in_len;
-  double *out = out_all + p * tn.out_len;
-  double *work = work_all != nullptr ? work_all + p * tn.ws_len : nullptr;
-  double *pg = gains + p * ((long)E_ * L::GAIN); // padded gains: what the rollout reads back
-  double *pw = wsp + p * ((long)Nn * L::WS);
+  const int cmN = isM ? c : N - 1, cuM = c < M ? c : M - 1;
+  const double *in = in_all + p * ts.in_len;
+  double *out = out_all + p * ts.out_len;
+  double *work = work_all != nullptr ? work_all + p * ts.ws_len : nullptr;
+  double *pg = gains + p * ((long)ts.E * L::GAIN); // padded gains: what the rollout reads back
+  double *pw = wsp + p * ((long)ts.Nn * L::WS);
 
-  double E[N];
-  sfor<0, N>([&](auto ii) { E[decltype(ii)::value] = (c == decltype(ii)::value) ? 1.0 : 0.0; });
+  double E[N], ZERO[N];
+  sfor<0, N>([&](auto ii) {
+    E[decltype(ii)::value] = (c == decltype(ii)::value) ? 1.0 : 0.0;
+    ZERO[decltype(ii)::value] = 0.0;
+  });
 
-  // Column `col` (clamped into the block) of a column-major rows x cols block, padded to N rows:
-  // dst[r] = on && r < rows ? blk[r + rows * col] : fill[r].  `rows`, `cols` are wave-uniform.
+  // Column `col` of a column-major rows x cols block, padded to N rows:
+  // dst[r] = on && col < cols && r < rows ? blk[r + rows * col] : fill[r].  Every load is issued
+  // unconditionally from a clamped (always readable) address and the padding is selected afterwards:
+  // no branches, the loads of a block travel together.
   auto load_col = [&](double (&dst)[N], const double *blk, const int rows, const int cols, const int col,
                       const bool on, const double (&fill)[N]) {
-    const int cc = col < cols ? col : (cols > 0 ? cols - 1 : 0);
-    const bool use = on && col < cols;
+    const bool any = rows > 0 && cols > 0;
+    const double *b = any ? blk : in; // an empty block: read the arena's first scalar instead (never used)
+    const int cc = any ? (col < cols ? col : cols - 1) : 0;
+    const bool use = on && any && col < cols;
+    const double *colp = b + (long)(any ? rows : 0) * cc;
     sfor<0, N>([&](auto ii) {
       constexpr int r = decltype(ii)::value;
-      double v = fill[r];
-      if (r < rows && cols > 0) { // wave-uniform
-        const double ld = blk[r + (long)rows * cc];
-        v = use ? ld : v;
-      }
-      dst[r] = v;
+      const double ld = colp[(any && r < rows) ? r : 0];
+      dst[r] = (use && r < rows) ? ld : fill[r];
     });
   };
-  double ZERO[N];
-  sfor<0, N>([&](auto ii) { ZERO[decltype(ii)::value] = 0.0; });
+  // element `idx` of a vector of `len` entries, `fill` past its end or when !on
+  auto load_elem = [&](const double *vec, const int len, const int idx, const bool on, const double fill) {
+    const double ld = (len > 0 ? vec : in)[(len > 0 && idx < len) ? idx : 0];
+    return (on && idx < len) ? ld : fill;
+  };
 
   int stat = 0;
-  double W[N], V[N], tv[N];
+  double W[N], V[N], tv[N]; // W / tv: of the node finished last; V: accumulator of the current parent
+  double Vc[N];             // [V | v] of the node finished last (its vector lane: v), for TS_CHILD_LIVE
 
-  // ---- backward: nodes in postorder (lqr.cpp:651) ------------------------------------------------
-  for (int idx = 0; idx < Nn; ++idx) {
-    const int j = tp.postorder[idx];
-    const int n = tn.sd[j];
-    const double *Qj = in + tn.oQ[j], *qj = in + tn.oq[j], *cj = in + tn.oc[j], *dj = in + tn.od[j];
-    // [V | v] = [Q | q]  (lqr.cpp:658, :744); identity columns on the padding lanes
-    if (isV) {
-      sfor<0, N>([&](auto ii) {
-        constexpr int r = decltype(ii)::value;
-        V[r] = r < n ? qj[r] : 0.0;
-      });
-    } else {
-      load_col(V, Qj, n, n, c, isM, E);
-      if (!isM)
-        sfor<0, N>([&](auto ii) { V[decltype(ii)::value] = 0.0; });
+  // ---- backward (lqr.cpp:645-731 and :738-796) ------------------------------------------------------
+  // Input blocks of a step (read-only data), requested together at the top of the step.
+  struct Pre {
+    double a[N], b[N], g[M], h[M], v[N], dl;
+  };
+  auto fetch = [&](const TreeStep &st, Pre &o) {
+    const int n = st.n, nc = st.nc, m = st.m;
+    if (st.flags & TS_LOAD_V) { // [Q | q] of `node`; identity columns on the padding lanes
+      const double *src = isV ? in + st.oq : in + st.oQ;
+      load_col(o.v, src, n, isV ? 1 : n, isV ? 0 : c, isM || isV, E);
     }
-    for (int ci = tp.child_offsets[j]; ci < tp.child_offsets[j + 1]; ++ci) { // lqr.cpp:660
-      const int e = tp.child_edges[ci], ch = tp.children[e];
-      const int nc = tn.sd[ch], m = tn.cd[e];
-      const double *Ae = in + tn.oA[e], *Be = in + tn.oB[e], *Me = in + tn.oM[e], *Re = in + tn.oR[e];
-      const double *re = in + tn.orr[e], *dch = in + tn.od[ch];
-      double *slot = pw + (long)ch * L::WS;
-      const int cmN = isM ? c : N - 1;
-      // W of the child from its spilled S (lqr.cpp:521-528)
-      {
-        const double dlc = (c < nc) ? dch[c < nc ? c : 0] : 1.0;
-        const double sdi = rsqrt_nr(dlc);
+    if (st.kind == 0) {
+      // column c of R (identity on the padding), column c of M^T = row c of M; vector lane: r
+      const bool anyR = m > 0, anyM = m > 0 && n > 0;
+      const double *Rc = (anyR ? in + st.oR : in) + (long)(anyR ? m : 0) * (c < m ? c : 0);
+      const double *Mr = (anyM ? in + st.oM : in) + (anyM && c < n ? c : 0);
+      const double *rv = anyR ? in + st.orr : in;
+      sfor<0, M>([&](auto jj) {
+        constexpr int q = decltype(jj)::value;
+        const int qq = (anyR && q < m) ? q : 0;
+        const double rl = Rc[qq], ml = Mr[(long)(anyM ? n : 0) * qq], rr_ = rv[qq];
+        o.g[q] = (q < m && c < m) ? rl : ((q == c) ? 1.0 : 0.0);
+        o.h[q] = (q < m) ? (isV ? rr_ : (c < n ? ml : 0.0)) : 0.0;
+      });
+      load_col(o.a, in + st.oA, nc, n, c, isM, ZERO); // column c of A (nc x n)
+      load_col(o.b, in + st.oB, nc, m, c, true, ZERO); // column c of B (nc x m)
+      o.dl = load_elem(in + st.odc, nc, c, true, 1.0); // delta of the child
+    } else {
+      load_col(o.a, in + st.oc, n, 1, 0, isV, ZERO); // c on the vector lane
+      load_col(o.b, in + st.od, n, 1, 0, isV, ZERO); // delta on the vector lane
+      o.dl = load_elem(in + st.od, n, c, true, 1.0);
+    }
+  };
+  auto backward_step = [&](const TreeStep &st, const Pre &pre) {
+    const int n = st.n;
+    if (st.flags & TS_LOAD_V) // [V | v] = [Q | q]  (lqr.cpp:658, :744)
+      sfor<0, N>([&](auto ii) { V[decltype(ii)::value] = pre.v[decltype(ii)::value]; });
+    if (st.kind == 0) { // one child edge of `node` (lqr.cpp:660-720)
+      const int e = st.edge, m = st.m;
+      double *slot = pw + (long)st.child * L::WS;
+      double F[N], Aaug[N], Hc[M], G[M], rinvG[M], H[M], K[M];
+      if (st.flags & TS_CHILD_LIVE) {
+        // the child is the node the previous step finished: W, t = tv and v = Vc are in registers
+        sfor<0, N>([&](auto kk) {
+          constexpr int k = decltype(kk)::value;
+          Aaug[k] = isV ? tv[k] : pre.a[k];
+          F[k] = isV ? Vc[k] : 0.0;
+        });
+      } else { // W of the child from its spilled S (lqr.cpp:521-528), t and v from its slot
+        const double sdi = rsqrt_nr(pre.dl);
         double Sc[N], scale[N];
         sfor<0, N>([&](auto ii) {
           constexpr int r = decltype(ii)::value;
           Sc[r] = slot[cmN * N + r];
           scale[r] = 0.0;
+          Aaug[r] = isV ? slot[N * N + 2 * N + r] : pre.a[r];
+          F[r] = isV ? slot[N * N + 3 * N + r] : 0.0;
         });
         spread<N, false, true>(scale, sdi, sdi); // sdi_r sdi_c
         sfor<0, N>([&](auto ii) {
@@ -137,37 +191,21 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
           W[r] = (E[r] - Sc[r]) * scale[r];
         });
       }
-      double F[N], Aaug[N], Bcol[N], Hc[M], G[M], rinvG[M], H[M], K[M];
-      // column c of R (identity on the padding), column c of M^T = row c of M; vector lane: r
       sfor<0, M>([&](auto jj) {
-        constexpr int q = decltype(jj)::value;
-        double gq = (q == c) ? 1.0 : 0.0, hq = 0.0;
-        if (q < m) { // wave-uniform
-          const double rl = Re[q + (long)m * (c < m ? c : 0)];
-          gq = c < m ? rl : gq;
-          const double rv = re[q];
-          const double ml = n > 0 ? Me[(c < n ? c : 0) + (long)n * q] : 0.0;
-          hq = isV ? rv : (c < n ? ml : 0.0);
-        }
-        G[q] = gq, H[q] = hq;
+        G[decltype(jj)::value] = pre.g[decltype(jj)::value];
+        H[decltype(jj)::value] = pre.h[decltype(jj)::value];
       });
-      // columns of A (nc x n) and B (nc x m); vector lane of Aaug / F: t and v of the child
-      load_col(Aaug, Ae, nc, n, c, isM, ZERO);
-      load_col(Bcol, Be, nc, m, c, true, ZERO);
-      if (isV)
-        sfor<0, N>([&](auto kk) { Aaug[decltype(kk)::value] = slot[N * N + 2 * N + decltype(kk)::value]; });
-      sfor<0, N>([&](auto kk) { F[decltype(kk)::value] = isV ? slot[N * N + 3 * N + decltype(kk)::value] : 0.0; });
       rank1x<N, N, true>(F, W, Aaug); // [F | g] = W [A | t] + [0 | v]  (lqr.cpp:703, :780-781)
       if (valid && isV)
         sfor<0, N>([&](auto ii) { slot[N * N + decltype(ii)::value] = F[decltype(ii)::value]; }); // g of the child
       // H_child = B^T W (lqr.cpp:692); G = R + H_child B (:693-694)
       sfor<0, M>([&](auto jj) { Hc[decltype(jj)::value] = 0.0; });
-      spreadx<M, N, false>(Hc, Bcol, W);
-      rank1x<M, N, true>(G, Hc, Bcol);
+      spreadx<M, N, false>(Hc, pre.b, W);
+      rank1x<M, N, true>(G, Hc, pre.b);
       const bool gfail = chol_ldl_dpp<M>(G, rinvG, c); // lqr.cpp:696-701
       if (stat == 0 && gfail)
         stat = 3; // G_FACTORIZATION_FAILURE
-      spreadx<M, N, false>(H, Bcol, F); // [H | h] = [M^T | r] + B^T [F | g]  (:704-705, :783-784)
+      spreadx<M, N, false>(H, pre.b, F); // [H | h] = [M^T | r] + B^T [F | g]  (:704-705, :783-784)
       sfor<0, M>([&](auto jj) { K[decltype(jj)::value] = H[decltype(jj)::value]; });
       ldl_solve_dpp<M>(G, rinvG, K); // [K | k] = -G^{-1} [H | h]  (:707-713, :785-791)
       sfor<0, M>([&](auto jj) { K[decltype(jj)::value] = -K[decltype(jj)::value]; });
@@ -175,7 +213,7 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
         double *gi = pg + (long)e * L::GAIN + c * M;
         sfor<0, M>([&](auto jj) { gi[decltype(jj)::value] = K[decltype(jj)::value]; });
         if (work != nullptr) { // LQR::Workspace::K (m x n, column-major) and k of the caller's work arena
-          double *dst = isV ? work + tn.ok[e] : work + tn.oK[e] + (long)m * c;
+          double *dst = isV ? work + st.ok : work + st.oK + (long)m * c;
           if (isV || c < n)
             sfor<0, M>([&](auto jj) {
               constexpr int q = decltype(jj)::value;
@@ -188,47 +226,53 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
       spreadx<N, N, false>(V, Aaug, F);
       spreadx<N, M, true>(V, K, H);
       asm volatile("" ::: "memory");
-    }
-    // the node itself: statuses, F / S, the affine terms the parent step needs (lqr.cpp:722-727)
-    double *mine = pw + (long)j * L::WS;
-    const double dl = (c < n) ? dj[c < n ? c : 0] : 1.0;
-    {
-      const unsigned long long bad = __ballot(c < n && dl <= 0.0);
-      if (stat == 0 && ((bad >> (lane & 48)) & 0xffffull) != 0)
-        stat = 1; // INVALID_DELTA
-    }
-    sfor<0, N>([&](auto ii) {
-      constexpr int r = decltype(ii)::value;
-      double cv = 0.0, dv = 0.0;
-      if (r < n) { // wave-uniform
-        const double cl = cj[r], dlr = dj[r];
-        cv = isV ? cl : 0.0, dv = isV ? dlr : 0.0;
+    } else { // the node itself: statuses, F / S, the affine terms the parent step needs (lqr.cpp:722-727)
+      double *mine = pw + (long)st.node * L::WS;
+      const double dl = pre.dl;
+      {
+        const unsigned long long bad = __ballot(c < n && dl <= 0.0);
+        if (stat == 0 && ((bad >> (lane & 48)) & 0xffffull) != 0)
+          stat = 1; // INVALID_DELTA
       }
-      tv[r] = cv - dv * V[r]; // c - delta o v on the vector lane, zeros elsewhere
-    });
-    if (valid && isV)
       sfor<0, N>([&](auto ii) {
         constexpr int r = decltype(ii)::value;
-        mine[N * N + 2 * N + r] = tv[r];
-        mine[N * N + 3 * N + r] = V[r];
+        tv[r] = pre.a[r] - pre.b[r] * V[r]; // c - delta o v on the vector lane, zeros elsewhere
+        Vc[r] = V[r];
       });
-    double X[N];
-    const bool ffail = node_factor<N>(V, dl, c, E, tv, W, X);
-    if (stat == 0 && ffail)
-      stat = 2; // F_FACTORIZATION_FAILURE
-    if (valid && isV) // h = S D^{-1/2} (c - delta o v)
-      sfor<0, N>([&](auto ii) { mine[N * N + N + decltype(ii)::value] = X[decltype(ii)::value]; });
-    if (valid && isM)
-      sfor<0, N>([&](auto ii) { mine[c * N + decltype(ii)::value] = X[decltype(ii)::value]; });
-    asm volatile("" ::: "memory");
+      if (valid && isV)
+        sfor<0, N>([&](auto ii) {
+          constexpr int r = decltype(ii)::value;
+          mine[N * N + 2 * N + r] = tv[r];
+          mine[N * N + 3 * N + r] = V[r];
+        });
+      double X[N];
+      const bool ffail = node_factor<N>(V, dl, c, E, tv, W, X);
+      if (stat == 0 && ffail)
+        stat = 2; // F_FACTORIZATION_FAILURE
+      if (valid && isV) // h = S D^{-1/2} (c - delta o v)
+        sfor<0, N>([&](auto ii) { mine[N * N + N + decltype(ii)::value] = X[decltype(ii)::value]; });
+      if (valid && isM)
+        sfor<0, N>([&](auto ii) { mine[c * N + decltype(ii)::value] = X[decltype(ii)::value]; });
+      asm volatile("" ::: "memory");
+    }
+  };
+  // (Requesting the blocks of step s + 1 before the arithmetic of step s -- two alternating register
+  // sets -- was measured and did not pay: 0.87 against 0.84 ms on the heterogeneous chain of the
+  // reference's benchmark family; the steps are bound by the store -> load round trips of the spill and
+  // by the serial pivot chains, not by the latency of the read-only inputs.)
+  for (int s = 0; s < ts.n_backward; ++s) {
+    const TreeStep st = ts.backward[s];
+    Pre pre;
+    fetch(st, pre);
+    backward_step(st, pre);
   }
-  // root (last in postorder): g = v + W (c - delta o v)  (lqr.cpp:798-819)
+  // root (the last node step): g = v + W (c - delta o v)  (lqr.cpp:798-819)
   {
     double F[N];
-    sfor<0, N>([&](auto ii) { F[decltype(ii)::value] = isV ? V[decltype(ii)::value] : 0.0; });
+    sfor<0, N>([&](auto ii) { F[decltype(ii)::value] = isV ? Vc[decltype(ii)::value] : 0.0; });
     rank1x<N, N, true>(F, W, tv);
     if (valid && isV) {
-      double *gn = pw + (long)tp.root * L::WS + N * N;
+      double *gn = pw + (long)ts.root * L::WS + N * N;
       sfor<0, N>([&](auto ii) { gn[decltype(ii)::value] = F[decltype(ii)::value]; });
     }
   }
@@ -237,77 +281,74 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
   // the rollout reads S / g / h / K / k written above by other lanes of this wave
   __syncthreads();
 
-  // ---- forward rollout in preorder (lqr.cpp:821-870); lane r < N owns row r -----------------------
+  // ---- forward rollout (lqr.cpp:821-870); lane r < N owns row r -----------------------------------
   auto sum4 = [](const double (&a)[4]) { return (a[0] + a[1]) + (a[2] + a[3]); };
-  const int cmN = isM ? c : N - 1, cuM = c < M ? c : M - 1;
-  for (int idx = 0; idx < Nn; ++idx) {
-    const int j = tp.preorder[idx];
-    const int n = tn.sd[j];
-    double x;
-    if (idx == 0) { // x_root = D^{1/2} h_root, y_root = g_root
-      const double *slot = pw + (long)j * L::WS;
-      const double dd = (c < n) ? in[tn.od[j] + (c < n ? c : 0)] : 1.0;
-      x = (dd * rsqrt_nr(dd)) * slot[N * N + N + cmN];
-      if (valid && c < n) {
-        out[tn.ox[j] + c] = x;
-        out[tn.oy[j] + c] = slot[N * N + cmN];
-      }
-      if (c >= n)
-        x = 0.0;
-    } else {
-      x = (c < n) ? out[tn.ox[j] + (c < n ? c : 0)] : 0.0; // written by this lane when the parent was rolled out
+  double xlast = 0.0; // x of the child the previous step produced
+  {                   // x_root = D^{1/2} h_root, y_root = g_root
+    const double *slot = pw + (long)ts.root * L::WS;
+    const int n = ts.root_n;
+    const double dd = load_elem(in + ts.root_od, n, c, true, 1.0);
+    const double x0 = (dd * rsqrt_nr(dd)) * slot[N * N + N + cmN];
+    if (valid && c < n) {
+      out[ts.root_ox + c] = x0;
+      out[ts.root_oy + c] = slot[N * N + cmN];
     }
-    for (int ci = tp.child_offsets[j]; ci < tp.child_offsets[j + 1]; ++ci) {
-      const int e = tp.child_edges[ci], ch = tp.children[e];
-      const int nc = tn.sd[ch], m = tn.cd[e];
-      const double *Ae = in + tn.oA[e], *Be = in + tn.oB[e];
-      const double *gi = pg + (long)e * L::GAIN;
-      const double *slot = pw + (long)ch * L::WS;
-      double KT[N], Arow[N], Brow[M], Wc[N];
+    xlast = c < n ? x0 : 0.0;
+  }
+  for (int s = 0; s < ts.n_forward; ++s) {
+    const TreeStep st = ts.forward[s];
+    const int e = st.edge, n = st.n, nc = st.nc, m = st.m;
+    double x;
+    if (st.flags & TS_CHILD_LIVE) {
+      x = xlast;
+    } else {
+      const double xl = out[(c < n) ? st.oxp + c : 0]; // written by this lane when the parent was rolled out
+      x = (c < n) ? xl : 0.0;                           // (out_len > 0 is guaranteed by the host)
+    }
+    const double *gi = pg + (long)e * L::GAIN;
+    const double *slot = pw + (long)st.child * L::WS;
+    double KT[N], Arow[N], Brow[M], Wc[N];
+    {
+      const bool anyA = nc > 0 && n > 0, anyB = nc > 0 && m > 0;
+      const double *Ar = (anyA ? in + st.oA : in) + (anyA && c < nc ? c : 0); // row c of A (nc x n)
+      const double *Br = (anyB ? in + st.oB : in) + (anyB && c < nc ? c : 0); // row c of B (nc x m)
       sfor<0, N>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
-        KT[k] = gi[k * M + cuM];  // padded gains: zeros on the padding
+        KT[k] = gi[k * M + cuM];   // padded gains: zeros on the padding
         Wc[k] = slot[cmN * N + k]; // S symmetric: row c = column c
-        double a = 0.0;
-        if (k < n && nc > 0) { // wave-uniform: row c of A (nc x n)
-          const double al = Ae[(c < nc ? c : 0) + (long)nc * k];
-          a = c < nc ? al : 0.0;
-        }
-        Arow[k] = a;
+        const double al = Ar[(long)(anyA ? nc : 0) * ((anyA && k < n) ? k : 0)];
+        Arow[k] = (k < n && c < nc) ? al : 0.0;
       });
       sfor<0, M>([&](auto jj) {
         constexpr int q = decltype(jj)::value;
-        double b = 0.0;
-        if (q < m && nc > 0) {
-          const double bl = Be[(c < nc ? c : 0) + (long)nc * q];
-          b = c < nc ? bl : 0.0;
-        }
-        Brow[q] = b;
+        const double bl = Br[(long)(anyB ? nc : 0) * ((anyB && q < m) ? q : 0)];
+        Brow[q] = (q < m && c < nc) ? bl : 0.0;
       });
-      const double kk0 = gi[N * M + cuM], gg = slot[N * N + cmN], hh = slot[N * N + N + cmN];
-      const double dd = (c < nc) ? in[tn.od[ch] + (c < nc ? c : 0)] : 1.0;
-      const double sdi = rsqrt_nr(dd), sdv = dd * sdi;
-      double acc[4] = {kk0, 0.0, 0.0, 0.0};
-      dotv<N, true>(acc, x, KT);
-      const double u = sum4(acc); // u = k + K x  (lqr.cpp:856-857)
-      double az[4] = {0.0, 0.0, 0.0, 0.0};
-      dotv<N, true>(az, x, Arow);
-      dotv<M, true>(az, u, Brow);
-      const double zeta = sum4(az) * sdi; // D^{-1/2} (A x + B u)
-      double as[4] = {0.0, 0.0, 0.0, 0.0};
-      dotv<N, true>(as, zeta, Wc);
-      const double sz = sum4(as);
-      const double xc = sdv * (sz + hh);                   // x_c = D^{1/2} (S zeta + h)
-      const double yc = __builtin_fma(sdi, zeta - sz, gg); // y_c = g_c + D^{-1/2} (zeta - S zeta)
-      if (valid) {
-        if (c < m)
-          out[tn.ou[e] + c] = u;
-        if (c < nc) {
-          out[tn.ox[ch] + c] = xc;
-          out[tn.oy[ch] + c] = yc;
-        }
+    }
+    const double kk0 = gi[N * M + cuM], gg = slot[N * N + cmN], hh = slot[N * N + N + cmN];
+    const double dd = load_elem(in + st.odc, nc, c, true, 1.0);
+    const double sdi = rsqrt_nr(dd), sdv = dd * sdi;
+    double acc[4] = {kk0, 0.0, 0.0, 0.0};
+    dotv<N, true>(acc, x, KT);
+    const double u = sum4(acc); // u = k + K x  (lqr.cpp:856-857)
+    double az[4] = {0.0, 0.0, 0.0, 0.0};
+    dotv<N, true>(az, x, Arow);
+    dotv<M, true>(az, u, Brow);
+    const double zeta = sum4(az) * sdi; // D^{-1/2} (A x + B u)
+    double as[4] = {0.0, 0.0, 0.0, 0.0};
+    dotv<N, true>(as, zeta, Wc);
+    const double sz = sum4(as);
+    const double xc = sdv * (sz + hh);                   // x_c = D^{1/2} (S zeta + h)
+    const double yc = __builtin_fma(sdi, zeta - sz, gg); // y_c = g_c + D^{-1/2} (zeta - S zeta)
+    if (valid) {
+      if (c < m)
+        out[st.ou + c] = u;
+      if (c < nc) {
+        out[st.oxc + c] = xc;
+        out[st.oyc + c] = yc;
       }
     }
+    xlast = c < nc ? xc : 0.0;
   }
 }
 

@@ -11,8 +11,8 @@ namespace sipamd {
 struct TreeClass {
   int n, m; // padded state / control dimension of the class
   const char *name;
-  hipError_t (*launch)(const TreeTopo &tp, const TreeNative &tn, const double *input, double *output, double *work,
-                       double *pgains, double *spill, int32_t *status, long batch, hipStream_t s);
+  hipError_t (*launch)(const TreeSchedule &ts, const double *input, double *output, double *work, double *pgains,
+                       double *spill, int32_t *status, long batch, hipStream_t s);
 };
 
 // Smallest size class that holds a tree whose largest state / control dimensions are max_n / max_m;
