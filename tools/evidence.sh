@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): the measurements a round's profiles/ is made from.
+# usage: tools/evidence.sh <tag>      (output under gpurun_out/<tag>/ and gpurun_out/prof/<tag>_*)
+set -o pipefail
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || exit 1
+timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1
+echo "pytest rc=$?" >> $OUT/pytest.log
+tail -3 $OUT/pytest.log
+for w in c3 c2 c4 kkt; do
+  timeout -k 10 200 python bench.py --workload $w --steps 30 --warmup 5 > $OUT/bench_$w.json 2> $OUT/bench_$w.err || echo "bench $w failed"
+done
+timeout -k 10 200 python tests/bench_kkt.py --theta 8 --steps 10 2>/dev/null | tail -1 > $OUT/bench_theta8.json
+timeout -k 10 200 python tools/bench_tree.py 2>/dev/null | tail -1 > $OUT/bench_tree.json
+timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c3 > $OUT/prof_c3.log 2>&1
+timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c4 --workload c4 > $OUT/prof_c4.log 2>&1
+timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c2 --workload c2 > $OUT/prof_c2.log 2>&1
+# counters that could separate DRAM from Infinity-Cache traffic (MI355X_MICROARCH.md: FETCH_SIZE counts fabric requests)
+(rocprofv3 -L 2>/dev/null || rocprofv3 --list-avail 2>/dev/null) | grep -iE "HBM|DRAM|MALL|EA0?_|TCC_EA|MC_|UMC|DF_|TCC_.*(REQ|MISS|HIT)" | head -150 > $OUT/counters_memory_side.txt
+echo "evidence done: $OUT"
