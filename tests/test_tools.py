@@ -101,3 +101,33 @@ def test_shipped_kernels_are_hazard_free():
             staged += 1
             assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", m.group(2)), m.group(1) + " uses scratch"
     assert staged >= 10
+
+
+def _wait_probs(text):
+    return chk.check_counted_waits(chk.parse_kernel(text.strip().split("\n")), "k")
+
+
+def test_counted_vmcnt_waits_must_not_reach_an_older_dma_group():
+    """`s_waitcnt vmcnt(k)` behind LDS-DMA staging (chain_qw16.hpp): the k youngest vector-memory
+    operations may be spill stores and / or the NEWEST DMA group, never part of a group before it."""
+    dma = "\tglobal_load_lds_dwordx4 v[2:3], off"
+    store = "\tglobal_store_dwordx2 v[4:5], v[6:7], off"
+    group_a, group_b = "\n".join([dma] * 2), "\n".join([dma] * 2)
+    ok = f"{group_a}\n{store}\n{store}\n{group_b}\n\ts_waitcnt vmcnt(2)\n\tds_read_b64 v[8:9], v1"
+    assert _wait_probs(ok) == []                                   # exactly the newest group stays in flight
+    assert _wait_probs(ok.replace("vmcnt(2)", "vmcnt(4)")) == []   # ... plus the stores before it
+    assert len(_wait_probs(ok.replace("vmcnt(2)", "vmcnt(5)"))) == 1  # one operation of group A too: stale image
+    stores = f"{group_a}\n{store}\n{store}\n{store}\n\ts_waitcnt vmcnt(3)"
+    assert _wait_probs(stores) == []
+    # a branch that skips the stores changes nothing for a wait that only covers the newest group
+    branchy = f"{group_a}\n\ts_cbranch_execz .LBB0_1\n{store}\n.LBB0_1:\n{group_b}\n\ts_waitcnt vmcnt(2)"
+    assert _wait_probs(branchy) == []
+    # known limit of the check: where two groups are ADJACENT on a path (the store between them skipped), a
+    # wait that reaches from one into the other is one unbroken DMA run and is not told apart
+    assert len(_wait_probs(branchy.replace("vmcnt(2)", "vmcnt(3)"))) == 0
+    crossing = f"{group_a}\n{store}\n{group_b}\n{store}\n\ts_waitcnt vmcnt(5)"
+    assert len(_wait_probs(crossing)) == 1
+    # scratch traffic in an LDS-DMA kernel shifts every count
+    assert len(_wait_probs(f"{dma}\n\tscratch_store_dword off, v1, s0\n\ts_waitcnt vmcnt(0)")) == 1
+    # kernels without LDS-DMA are not looked at
+    assert _wait_probs(f"{store}\n\ts_waitcnt vmcnt(1)") == []

@@ -148,6 +148,92 @@ def check(items, name):
     return problems
 
 
+VMEM_PREFIX = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic",
+               "flat_load", "flat_store", "scratch_load", "scratch_store")
+
+
+def is_vmem(item):
+    return item[0] == "ins" and item[1].startswith(VMEM_PREFIX)
+
+
+def is_lds_dma(item):
+    return item[0] == "ins" and (item[1].startswith("global_load_lds") or
+                                 (item[1].startswith("buffer_load") and " lds" in (" " + item[3])))
+
+
+def check_counted_waits(items, name):
+    """The staged kernels conclude from a COUNTED wait that an LDS-DMA group has landed
+    (chain_qw16.hpp): `s_waitcnt vmcnt(k)`, k > 0, lets the k youngest vector-memory operations stay in
+    flight, so that is only right if, on EVERY path into the wait, those k youngest operations are not
+    the DMA whose image the code behind the wait reads.  Two patterns are legitimate there:
+      (stores)  the k youngest operations are all non-DMA (the spill stores of the previous stage);
+      (group)   youngest-first, the operations are [non-DMA]* then DMA only: the wait then reaches at most
+                into the NEWEST DMA group (a longer wait than needed is harmless), never across older
+                non-DMA operations into a group before it.
+    Flagged: a path with fewer than k vector-memory operations before the kernel entry is fine (everything
+    has landed); a path whose k youngest operations run DMA -> non-DMA -> DMA (the wait would leave part of
+    an OLDER group in flight), and any LDS-DMA kernel that spills registers (scratch traffic would shift
+    every count).  Not proven by this check: that a wait meant to cover only stores has at least k stores
+    in front of it on every path, and reaches between two groups that are adjacent on a path."""
+    label_at = {it[1]: i for i, it in enumerate(items) if it[0] == "label"}
+    branch_preds = {}
+    for i, it in enumerate(items):
+        if it[0] == "ins" and (it[1].startswith("s_cbranch") or it[1] == "s_branch"):
+            tgt = it[2][0] if it[2] else None
+            if tgt in label_at:
+                branch_preds.setdefault(label_at[tgt], []).append(i)
+    problems = []
+    if not any(is_lds_dma(it) for it in items):
+        return problems
+    for it in items:
+        if it[0] == "ins" and it[1].startswith("scratch_"):
+            problems.append((name, it[3], "", 0, "LDS-DMA kernel with scratch traffic: counted vmcnt waits are unsafe"))
+            break
+    for i, it in enumerate(items):
+        if it[0] != "ins" or it[1] != "s_waitcnt":
+            continue
+        m = re.search(r"vmcnt\((\d+)\)", it[3])
+        if not m or int(m.group(1)) == 0:
+            continue
+        k = int(m.group(1))
+        # depth-first over backward paths; state = (index, ops seen, phase) with phase 0: only non-DMA seen,
+        # 1: inside the DMA run, 2: non-DMA after a DMA run (a later DMA is then the violation)
+        stack = [(i - 1, 0, 0)]
+        seen = set()
+        bad = None
+        while stack and bad is None:
+            j, count, phase = stack.pop()
+            while j >= 0 and count < k:
+                if (j, count, phase) in seen:
+                    break
+                seen.add((j, count, phase))
+                cur = items[j]
+                if cur[0] == "label":
+                    for b in branch_preds.get(j, []):
+                        stack.append((b, count, phase))
+                    q = j - 1
+                    while q >= 0 and items[q][0] == "label":
+                        q -= 1
+                    if q >= 0 and items[q][1] in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                        break
+                    j -= 1
+                    continue
+                if is_vmem(cur):
+                    count += 1
+                    dma = is_lds_dma(cur)
+                    if phase == 0 and dma:
+                        phase = 1
+                    elif phase == 1 and not dma:
+                        phase = 2
+                    elif phase == 2 and dma:
+                        bad = cur[3]
+                        break
+                j -= 1
+        if bad is not None:
+            problems.append((name, bad, it[3], k, "counted vmcnt reaches across non-DMA operations into an older LDS-DMA group"))
+    return problems
+
+
 def main():
     path = sys.argv[1]
     wanted = sys.argv[2:]
@@ -171,7 +257,7 @@ def main():
             continue
         items = parse_kernel(body)
         ndpp = sum(1 for it in items if it[0] == "ins" and dpp_source(it) is not None)
-        probs = check(items, name)
+        probs = check(items, name) + check_counted_waits(items, name)
         checked += 1
         print(f"{name}: {ndpp} DPP instructions, {len(probs)} hazard(s)")
         for p in probs[:20]:
