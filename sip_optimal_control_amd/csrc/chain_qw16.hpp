@@ -95,6 +95,7 @@ __device__ __forceinline__ double rcp_nr(double d) {
 template <int S>
 __device__ __forceinline__ bool chol_ldl_dpp(double (&A)[S], double (&dinv)[S],
                                              const int c) {
+#ifdef SIP_QW16_CHOL_SELECT // the round-1 form: a ballot + scalar OR per pivot, the update column by two selects
   // The pivot is replicated over its row, so the comparison result is
   // row-uniform: collect it as a wave mask (one v_cmp + one s_or per pivot).
   unsigned long long failmask = 0;
@@ -110,6 +111,26 @@ __device__ __forceinline__ bool chol_ldl_dpp(double (&A)[S], double (&dinv)[S],
     rank1<S - k - 1, k, true, false>(A + k + 1, A + k + 1, upd);
   });
   return ((failmask >> (__lane_id() & 63)) & 1ull) != 0;
+#else
+  // The smallest pivot so far (row-replicated like the pivots): one v_min_f64 per pivot and one
+  // comparison at the end say "some pivot <= 0".  v_min_f64 returns the other operand for a NaN,
+  // so a NaN pivot passes as it passes Eigen's `x <= 0` test.
+  double dmin = __builtin_inf();
+  sfor<0, S>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    const double d = bcast<k>(A[k]);
+    asm("v_min_f64 %0, %1, %2" : "=v"(dmin) : "v"(dmin), "v"(d));
+    // lane j > k: Lt(j,k) (by symmetry its own A[k]), zero on the finished columns -- a multiply by
+    // a loop-invariant 0/1 that does not wait for the reciprocal
+    const double own = A[k] * ((c > k && c < S) ? 1.0 : 0.0);
+    const double y2 = rcp_nr(d);
+    dinv[k] = y2;
+    const double upd = own * y2; // Lt(j,k) / d_k
+    // A(i,j) -= Lt(i,k) Lt(j,k) / d_k, i > k, lanes j > k
+    rank1<S - k - 1, k, true, false>(A + k + 1, A + k + 1, upd);
+  });
+  return dmin <= 0.0;
+#endif
 }
 
 // X <- (Lt D^-1 Lt^T)^{-1} X for X held one column per lane (any lane of the
@@ -234,6 +255,18 @@ template <int PIECES>
 struct StageDma {
   static constexpr int INSTR = (4 * PIECES + 63) / 64;
   static constexpr int BYTES = INSTR * 1024;
+  static constexpr int ROW_BYTES = PIECES * 16; // problem rr's image starts at rr * ROW_BYTES
+  // The instruction's immediate offset is added to the global AND to the LDS address, so four
+  // consecutive instructions (LDS images 1 KiB apart) share one M0 value: instruction j carries
+  // the immediate (j % 4) * 1024, its lanes' global offsets are lowered by as much, and M0 moves
+  // once per group of four (one s_add + its wait state instead of four).  BIAS keeps the lowered
+  // offsets non-negative (they are zero-extended into the address).
+#ifdef SIP_QW16_DMA_PLAIN
+  static constexpr int GROUP = 1;
+#else
+  static constexpr int GROUP = 4;
+#endif
+  static constexpr unsigned BIAS = (GROUP - 1) * 1024u;
   unsigned off[INSTR > 0 ? INSTR : 1];
   __device__ __forceinline__ void init(const int lane,
                                        const unsigned problem_stride_bytes,
@@ -245,7 +278,7 @@ struct StageDma {
       unsigned rr = q / PIECES;
       const unsigned within = q - rr * PIECES;
       rr = rr < max_rel ? rr : max_rel;
-      off[j] = rr * problem_stride_bytes + within * 16u;
+      off[j] = rr * problem_stride_bytes + within * 16u + BIAS - (unsigned)(j % GROUP) * 1024u;
     });
   }
   // base: wave-uniform pointer to the region of the wave's first problem.
@@ -257,10 +290,58 @@ struct StageDma {
     // identically predicated tails in a row (e.g. 4 * 305 and 4 * 17 pieces: lanes < 4 both) were
     // tail-merged by the compiler into ONE instruction whose LDS base -- a wave-uniform M0 value --
     // became a per-lane PHI read with v_readfirstlane, which scattered one image into the other.
+    const char *lowered = base - BIAS;
     sfor<0, INSTR>([&](auto jj) {
       constexpr int j = decltype(jj)::value;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off[j]),
-                                       (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, AUX);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(lowered + off[j]),
+                                       (__attribute__((address_space(3))) void *)(dst + (j - j % GROUP) * 1024), 16,
+                                       (j % GROUP) * 1024, AUX);
+    });
+  }
+};
+
+// The same staging with every instruction inside ONE problem's region: the image of problem rr
+// starts at rr * IP KiB (IP = instructions per problem, the region padded to whole instructions)
+// and instruction (rr, jj) moves its pieces [64 jj, 64 jj + 64).  All lanes then use the same byte
+// offset 16 * lane for every instruction (one more for the last instruction of a problem, whose
+// lanes past the last piece re-read it), the problem's base is wave-uniform, and jj rides in the
+// immediate offset: 2 offset registers instead of one (64-bit) per instruction, one address add
+// per problem and one M0 value per four instructions.
+template <int PIECES>
+struct StageDmaRows {
+  static constexpr int IP = (PIECES + 63) / 64;
+  static constexpr int INSTR = 4 * IP;
+  static constexpr int ROW_BYTES = IP * 1024;
+  static constexpr int BYTES = 4 * ROW_BYTES;
+  static constexpr bool RAGGED = PIECES % 64 != 0;
+  unsigned vo_main, vo_tail;
+  unsigned long long row[4]; // wave-uniform byte offset of problem rr's region (clamped at the batch end)
+  __device__ __forceinline__ void init(const int lane,
+                                       const unsigned problem_stride_bytes,
+                                       const unsigned max_rel) {
+    vo_main = (unsigned)lane * 16u;
+    const unsigned last = (unsigned)(PIECES - 1 - 64 * (IP - 1)); // last piece of the last instruction
+    vo_tail = ((unsigned)lane < last ? (unsigned)lane : last) * 16u;
+    sfor<0, 4>([&](auto rq) {
+      constexpr unsigned r = decltype(rq)::value;
+      row[r] = (unsigned long long)(r < max_rel ? r : max_rel) * problem_stride_bytes;
+    });
+  }
+  template <int AUX = 0>
+  __device__ __forceinline__ void issue(const char *base, lds_char *dst,
+                                        const int lane) const {
+    // whole-wave instructions only (see StageDma::issue)
+    sfor<0, 4>([&](auto rq) {
+      constexpr int r = decltype(rq)::value;
+      const char *region = base + row[r];
+      sfor<0, IP>([&](auto jq) {
+        constexpr int jj = decltype(jq)::value;
+        constexpr int g = jj / 4; // immediates reach 3 KiB: a new base every four instructions
+        const unsigned vo = (RAGGED && jj == IP - 1) ? vo_tail : vo_main;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(region + g * 4096 + vo),
+            (__attribute__((address_space(3))) void *)(dst + r * ROW_BYTES + g * 4096), 16, (jj % 4) * 1024, AUX);
+      });
     });
   }
 };
@@ -271,9 +352,23 @@ struct StagedCfg {
   using L = ChainLayout<N, M>;
   static constexpr int WSN = // S | g | h, even number of scalars
       WPACK ? ((N * (N + 1) / 2 + 2 * N + 1) / 2) * 2 : L::WSN;
-  // backward: whole stage block of mats + of vecs
-  using BM = StageDma<(L::NODE + L::EDGE) / 2>;
+  // backward: whole stage block of mats + of vecs.  The per-problem form of the mats stream pads
+  // every problem to whole instructions; it is taken unless that padding costs a wavefront per CU
+  // (160 KiB of LDS: four wavefronts need <= 40 KiB each).
   using BV = StageDma<(L::VNODE + L::VEDGE) / 2>;
+  using BMflat = StageDma<(L::NODE + L::EDGE) / 2>;
+  using BMrows = StageDmaRows<(L::NODE + L::EDGE) / 2>;
+  static constexpr int SCR_BYTES_ = ((4 * 2 * N + N) * 8 + 1023) / 1024 * 1024;
+  static constexpr int waves_per_cu(int bm_bytes) {
+    const int per_wave = 2 * (bm_bytes + BV::BYTES) + SCR_BYTES_;
+    const int w = 163840 / per_wave;
+    return w > 4 ? 4 : w;
+  }
+#ifdef SIP_QW16_DMA_FLAT
+  using BM = BMflat;
+#else
+  using BM = std::conditional_t<waves_per_cu(BMrows::BYTES) >= waves_per_cu(BMflat::BYTES), BMrows, BMflat>;
+#endif
   static constexpr int B_BYTES = BM::BYTES + BV::BYTES;
   // forward: A|B, gains, S|g|h of the child, delta of the child
   using FA = StageDma<(N * N + N * M) / 2>;
@@ -371,17 +466,19 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     E[r] = (c == r) ? 1.0 : 0.0;
   });
 
-  // Offsets of S(r, k), k = 0..N-1, r = this lane's row, inside a spill slot.
-  int woff[N];
-  sfor<0, N>([&](auto kk) {
-    constexpr int k = decltype(kk)::value;
-    if constexpr (WPACK) {
-      const int lo = k < cm ? k : cm, hi = k < cm ? cm : k; // S(hi, lo)
-      woff[k] = lo * N - (lo * (lo - 1)) / 2 + (hi - lo);
-    } else {
-      woff[k] = cm * N + k; // S symmetric: row r = column r
-    }
-  });
+  // Offsets of S(r, k), k = 0..N-1, r = this lane's row, inside a spill slot (built where the
+  // spill is read -- the mode-2 sweep and the rollout -- not carried through the backward sweep).
+  auto spill_row_offsets = [&](int(&woff)[N]) {
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      if constexpr (WPACK) {
+        const int lo = k < cm ? k : cm, hi = k < cm ? cm : k; // S(hi, lo)
+        woff[k] = lo * N - (lo * (lo - 1)) / 2 + (hi - lo);
+      } else {
+        woff[k] = cm * N + k; // S symmetric: row r = column r
+      }
+    });
+  };
 
   int stat = 0;
   double W[N], V[N], t[N], vch[N];
@@ -462,11 +559,14 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       tv[r] = nt.cv[r] - nt.dv[r] * V[r];
     });
     if constexpr (STAGED) {
-      if (isV) {
-        sfor<0, N>([&](auto ii) {
-          constexpr int r = decltype(ii)::value;
-          my_t[r] = tv[r];
-          my_v[r] = V[r];
+      if (isV) { // 16-byte pairs (N even): ds_write_b128 at immediate offsets from one address
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) d2 lds_d2;
+        lds_d2 *const t2 = (lds_d2 *)my_t, *const v2 = (lds_d2 *)my_v;
+        sfor<0, N / 2>([&](auto kk) {
+          constexpr int k = decltype(kk)::value;
+          t2[k] = d2{tv[2 * k], tv[2 * k + 1]};
+          v2[k] = d2{V[2 * k], V[2 * k + 1]};
         });
       }
     } else {
@@ -597,8 +697,6 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       dotv<N, true>(acc, gd, Bcol);
       hd = nv[L::VNODE + cu] + sum4(acc);
     }
-    asm volatile("" ::: "memory");
-    load_tail(nm, nv, nt); // c, delta: in flight behind the gain solve
     // [K | k] = -G^{-1} [H | h]   (lqr.cpp:707-713, :785-791)
     sfor<0, M>(
         [&](auto jj) { K[decltype(jj)::value] = H[decltype(jj)::value]; });
@@ -646,6 +744,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     // [V | v] = [Q | q] + A^T [F | g] + K^T [H | h]  (lqr.cpp:715-719,:793-794)
     // (Aaug's vector lane is never broadcast: spread reads lanes < N only)
     spreadx<N, N, false>(Vn, Aaug, F);
+    asm volatile("" ::: "memory");
+    load_tail(nm, nv, nt); // c, delta of the node: in flight behind the K^T H product (F and A are dead by now)
+    asm volatile("" ::: "memory");
     spreadx<N, M, true>(Vn, K, H);
     sfor<0, N>(
         [&](auto ii) { V[decltype(ii)::value] = Vn[decltype(ii)::value]; });
@@ -686,13 +787,20 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   SIP_STAMP(ts_term);
 
   // ---- backward recursion over edges i = T-1 .. 0 -------------------------
-  for (int i = T - 1; i >= 0; --i) {
+  // One stage of the sweep; `par` = i & 1 selects the LDS buffer stage i landed in.  The staged
+  // kernel runs the loop two stages per trip with the parity a compile-time constant, so every LDS
+  // address of a stage (buffer + row + lane-dependent column offsets) is loop-invariant and leaves
+  // the loop instead of being rebuilt by ~50 vector instructions per stage.
+  auto stage_step = [&](const int i, auto par) {
     SIP_STAMP(ts_a);
 #ifdef SIP_LQR_STAMPS
     seg_last = ts_a;
+    if (stamps != nullptr && lane == 0 && i < 64) // per-stage trace behind the per-wave records
+      stamps[(long)gridDim.x * 24 + (long)blockIdx.x * 128 + i] = ts_a;
 #endif
     if constexpr (STAGED) {
-      lds_char *buf = lds + (i & 1) * C::B_BYTES;
+      constexpr int PAR = decltype(par)::value;
+      lds_char *buf = lds + PAR * C::B_BYTES;
       // Stage i has landed.  The N buffer stores of the packed-W spill are the
       // last vector-memory operations of the previous node (every lane issues
       // them, out-of-range ones included), so they may stay in flight:
@@ -705,7 +813,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       acc_bwait += ts_b - ts_a;
       SIP_SEG(0);
       if (i > 0) { // next stage streams into the other buffer meanwhile
-        lds_char *nbuf = lds + ((i - 1) & 1) * C::B_BYTES;
+        lds_char *nbuf = lds + (PAR ^ 1) * C::B_BYTES;
         dma_bm.template issue<SIP_LQR_NT_IN>((const char *)(mats + p0 * mats_len + (long)(i - 1) * STG),
                      nbuf, lane);
         dma_bv.template issue<SIP_LQR_NT_IN>(
@@ -713,7 +821,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
             nbuf + C::BM::BYTES, lane);
         asm volatile("" ::: "memory"); // stores of this stage stay younger
       }
-      lds_cdouble *nm = (lds_cdouble *)(buf + rr * (STG * 8));
+      lds_cdouble *nm = (lds_cdouble *)(buf + rr * C::BM::ROW_BYTES);
       lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + rr * (VSTG * 8));
       SIP_SEG(1);
       NodeTail nt;
@@ -728,6 +836,29 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       finish_node(i, nt);
     }
     SIP_SEG(9);
+  };
+#ifdef SIP_QW16_NO_PARITY_UNROLL
+  constexpr bool kParityUnroll = false;
+#else
+  constexpr bool kParityUnroll = STAGED;
+#endif
+  if constexpr (kParityUnroll) {
+    // trips over (odd i, i - 1); the first trip of an odd T has no odd stage
+    for (int i = (T - 1) | 1; i >= 1; i -= 2) {
+      if (i <= T - 1)
+        stage_step(i, std::integral_constant<int, 1>{});
+      stage_step(i - 1, std::integral_constant<int, 0>{});
+    }
+  } else if constexpr (STAGED) {
+    for (int i = T - 1; i >= 0; --i) {
+      if (i & 1)
+        stage_step(i, std::integral_constant<int, 1>{});
+      else
+        stage_step(i, std::integral_constant<int, 0>{});
+    }
+  } else {
+    for (int i = T - 1; i >= 0; --i)
+      stage_step(i, std::integral_constant<int, 0>{});
   }
 
   SIP_STAMP(ts_bwd);
@@ -761,6 +892,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     // ---- mode 2: the affine sweep alone (lqr.cpp:738-796), vectors distributed over the lanes ----
     // Node step: t = c - delta o v; h = S D^{-1/2} t (spilled for the rollout); returns
     // W t = D^{-1/2} (I - S) D^{-1/2} t.
+    int woff[N];
+    spill_row_offsets(woff);
     auto node_step = [&](const int i, const double v_) {
       const double dl = pm[(long)i * STG + N * N + cm];
       const double t_ = pv[(long)i * VSTG + N + cm] - dl * v_;
@@ -879,6 +1012,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       ps[N + c] = y;
     }
   }
+  int woff[N];
+  spill_row_offsets(woff);
   int fbuf = 0; // LDS buffer of stage i = i % F_NBUF
   for (int i = 0; i < T; ++i) {
     double KT[N], Arow[N], Brow[M], Wc[N];
@@ -900,6 +1035,10 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       dd = dp[cm];
     };
     SIP_STAMP(ts_a);
+#ifdef SIP_LQR_STAMPS
+    if (stamps != nullptr && lane == 0 && i < 64)
+      stamps[(long)gridDim.x * 24 + (long)blockIdx.x * 128 + 64 + i] = ts_a;
+#endif
     if constexpr (STAGED) {
       lds_char *buf = lds + (fbuf * C::F_BYTES);
       // Stage i+1's LDS-DMA (F_GLDS instructions, the youngest vector-memory

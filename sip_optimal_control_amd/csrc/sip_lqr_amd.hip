@@ -84,6 +84,9 @@ using sipamd::KernelEntry;
     sipamd::mf32::Layout<M>::WSN, &launch_mf32<M> }
 
 const KernelEntry kKernels[] = {
+#ifdef SIP_QW16_QUICK // tools/ab_build.sh: the C3 kernel alone, for A/B timing of kernel variants
+    QW16_STAGED(12, 4),
+#else
     MF32(8), QW16_STAGED_MR(12, 4), QW16_STAGED_MR(4, 2), QW16_DIRECT(12, 4),
     QW16_DIRECT(4, 2),  QW16_DIRECT(1, 1), QW16_DIRECT(2, 1),
     QW16_DIRECT(3, 2),  QW16_DIRECT_MR(8, 3),
@@ -99,6 +102,7 @@ const KernelEntry kKernels[] = {
     QW16_DIRECT(15, 8),
     // n = 16 (in the reference's benchmark grid): distributed-vector mode, see chain_qw16.hpp
     QW16_DIRECT_MR(16, 1), QW16_DIRECT_MR(16, 2), QW16_DIRECT_MR(16, 3), QW16_DIRECT_MR(16, 4), QW16_DIRECT(16, 8),
+#endif
 };
 
 // Every other shape n <= 16, m <= 8 (qw16_extra.hip, compiled in SIP_QW16_SLICES slices).

@@ -11,13 +11,15 @@ from sip_optimal_control_amd._lib import load_library
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 c4 = len(sys.argv) > 2 and sys.argv[2] == "c4"
 n, m, T = (32, 8, 100) if c4 else (12, 4, 50)
+if len(sys.argv) > 3:
+    T = int(sys.argv[3])  # horizon override: python tools/stamps.py 4096 c3 20
 dtype = torch.float32 if c4 else torch.float64
 shape = ChainShape(n, m, T)
 mats, vecs = synthetic.make_chain_batch(shape, batch, seed=1, device="cuda:0", dtype=dtype)
 solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device="cuda:0")
 lib = load_library()
 waves = batch if c4 else (batch + 3) // 4
-st = torch.zeros(waves * 24, dtype=torch.int64, device="cuda:0")
+st = torch.zeros(waves * (24 + 128), dtype=torch.int64, device="cuda:0")
 fn = ctypes.CDLL(os.environ["SIP_LQR_LIB"]).sip_lqr_debug_set_stamps
 fn.argtypes = [ctypes.c_void_p]
 sol = solver.empty_sol(); gains = solver.empty_gains()
@@ -25,7 +27,8 @@ for it in range(5):
     fn(ctypes.c_void_p(st.data_ptr()))
     solver.factor_solve(mats, vecs, sol, gains)
     torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(waves, 24).astype(np.float64)
+raw = st.cpu().numpy()
+s = raw[:waves * 24].reshape(waves, 24).astype(np.float64)
 tot = s[:, 4] - s[:, 0]
 print("kernel:", solver.kernel_name)
 print("waves", waves, "cycles per wave: total median %.0f  min %.0f max %.0f" % (np.median(tot), tot.min(), tot.max()))
@@ -44,3 +47,15 @@ names = ["wait DMA", "LDS reads + DMA issue", "F = W [A|t] (+g store)", "Hc, G p
 print("  backward segments, cycles per stage (median over waves):")
 for k in range(10):
     print("    %-36s %7.0f" % (names[k], np.median(s[:, 8 + k]) / T))
+
+if not c4:
+    tr = raw[waves * 24:].reshape(waves, 128).astype(np.float64)
+    for name, lo, end in (("backward", 0, s[:, 2]), ("forward", 64, s[:, 4])):
+        cols = tr[:, lo:lo + T]
+        if lo == 0:
+            cols = cols[:, ::-1]  # the backward loop runs i = T-1 .. 0
+        t = np.concatenate([cols, end[:, None]], axis=1)
+        d = np.median(np.diff(t, axis=1), axis=0)
+        print("  %s: cycles of each stage in loop order (median over waves):" % name)
+        for a in range(0, T, 10):
+            print("    " + " ".join("%6.0f" % v for v in d[a:a + 10]))
