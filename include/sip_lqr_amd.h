@@ -156,6 +156,23 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
                          const void *d_vecs, void *d_sol, void *d_gains,
                          int32_t *d_status, void *d_workspace, void *stream);
 
+/* The same fused sweep with the dynamics Jacobians read in place.  Replaces: the copy of ddyn_dx /
+ * ddyn_du into LQR::Input::A / B (helpers.cpp:365-366) followed by the loop body above -- the
+ * Newton-KKT step (sip_kkt_factor_solve) hands the Riccati sweep the Jacobians where the model
+ * callback left them instead of copying them into `mats`.
+ *   d_mats: per problem sip_lqr_split_mats_len() scalars: node blocks [Q | delta] as in the packed
+ *           chain layout, edge blocks [M | R] (no A, B);
+ *   d_ab  : stage i of problem p: A (n x n, column-major) then B (n x m, column-major) at
+ *           d_ab + (p * ab_problem_stride + i * ab_stage_stride) scalars.
+ * 16-byte aligned bases and strides.  Available (sip_lqr_has_split() == 1) for fp64 plans whose fused
+ * kernel is an LDS-staged one of the reference's Newton-KKT benchmark grid (n in {4, 6, 8, 12},
+ * m in {2, 4}); SIP_LQR_ERR_UNSUPPORTED otherwise.  Everything else as sip_lqr_factor_solve. */
+int sip_lqr_has_split(const sip_lqr_plan *plan);
+int64_t sip_lqr_split_mats_len(const sip_lqr_plan *plan);
+int sip_lqr_factor_solve_split(const sip_lqr_plan *plan, const void *d_mats, const void *d_ab,
+                               int64_t ab_problem_stride, int64_t ab_stage_stride, const void *d_vecs, void *d_sol,
+                               void *d_gains, int32_t *d_status, void *d_workspace, void *stream);
+
 /* Replaces: LQR::factor_with_status() alone (lqr.cpp:645-731; called by
  * CallbackProvider::factor, helpers.cpp:368).  Leaves the factor state in
  * d_workspace and the K part of d_gains for later sip_lqr_solve() calls.

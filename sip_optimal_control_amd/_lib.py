@@ -42,6 +42,9 @@ _SIGNATURES = {
     "sip_lqr_unpack_solution": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, _P]),
     "sip_lqr_unpack_gains": (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P]),
     "sip_lqr_factor_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "sip_lqr_has_split": (ctypes.c_int, [_P]),
+    "sip_lqr_split_mats_len": (ctypes.c_int64, [_P]),
+    "sip_lqr_factor_solve_split": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P, _P, _P]),
     "sip_lqr_factor": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "sip_lqr_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "sip_lqr_solve_multi_workspace_bytes": (ctypes.c_size_t, [_P, ctypes.c_int]),

@@ -94,6 +94,47 @@ class BatchedChainLQR:
             ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_factor_solve")
         return sol, gains, self.status
 
+    @property
+    def has_split(self):
+        """True when sip_lqr_factor_solve_split serves this plan (A | B read in place)."""
+        return bool(self._lib.sip_lqr_has_split(self._plan))
+
+    def split_inputs(self, mats):
+        """The inputs of factor_solve_split cut out of packed `mats` [batch, mats_len]: (qmr, ab) with
+        qmr [batch, split_mats_len] = node blocks [Q | delta], edge blocks [M | R], and ab [batch, T, n * (n + m)]
+        = A | B per stage.  A test / demo helper: callers of the split entry point have A | B elsewhere already."""
+        s = self.shape
+        n, m, T = s.n, s.m, s.T
+        node, edge, abn = n * n + n, n * n + 2 * n * m + m * m, n * n + n * m
+        stg = node + edge
+        body = mats[:, :T * stg].reshape(self.batch, T, stg)
+        qmr = torch.cat([torch.cat([body[:, :, :node], body[:, :, node + abn:]], dim=2).reshape(self.batch, -1),
+                         mats[:, T * stg:]], dim=1).contiguous()
+        assert qmr.shape[1] == int(self._lib.sip_lqr_split_mats_len(self._plan))
+        return qmr, body[:, :, node:node + abn].contiguous()
+
+    def factor_solve_split(self, qmr, ab, vecs, sol=None, gains=None, stream=None):
+        """factor_solve with the dynamics Jacobians read in place (sip_lqr_factor_solve_split): `ab` any
+        tensor whose element [p, i] holds A | B of stage i (strides taken from the tensor)."""
+        s = self.shape
+        if sol is None:
+            sol = self.empty_sol()
+        if gains is None:
+            gains = self.empty_gains()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        assert ab.dtype == torch.float64 and ab.stride(-1) == 1 and ab.shape[-1] >= s.n * (s.n + s.m)
+        _check(self._lib.sip_lqr_factor_solve_split(
+            self._plan, ctypes.c_void_p(qmr.data_ptr()), ctypes.c_void_p(ab.data_ptr()),
+            ctypes.c_int64(ab.stride(0)), ctypes.c_int64(ab.stride(1) if ab.dim() > 2 else 0),
+            self._ptr(vecs, self.batch, s.vecs_len, "vecs"),
+            self._ptr(sol, self.batch, s.vecs_len, "sol"),
+            self._ptr(gains, self.batch, s.gains_len, "gains"),
+            ctypes.c_void_p(self.status.data_ptr()),
+            ctypes.c_void_p(self.workspace.data_ptr()),
+            ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_factor_solve_split")
+        return sol, gains, self.status
+
     def factor(self, mats, gains=None, stream=None):
         """LQR::factor_with_status() alone (general engine): statuses, K part of gains,
         factor state kept in the workspace for later solve() calls."""

@@ -347,29 +347,38 @@ struct StageDmaRows {
 };
 
 // Byte sizes of the LDS images of the staged kernel (one wave per block).
-template <int N, int M, bool WPACK>
+// SPLIT (the Newton-KKT step, sip_lqr_factor_solve_split): A | B are not part of the mats stage
+// block -- [Q | delta | M | R] is -- and stream from a second array (the dynamics Jacobians where the
+// model callback left them), as an image of their own behind the mats image.
+template <int N, int M, bool WPACK, bool SPLIT = false>
 struct StagedCfg {
   using L = ChainLayout<N, M>;
+  static constexpr int AB = N * N + N * M;                      // A | B
+  static constexpr int STG = L::NODE + L::EDGE - (SPLIT ? AB : 0); // mats stage stride
   static constexpr int WSN = // S | g | h, even number of scalars
       WPACK ? ((N * (N + 1) / 2 + 2 * N + 1) / 2) * 2 : L::WSN;
   // backward: whole stage block of mats + of vecs.  The per-problem form of the mats stream pads
   // every problem to whole instructions; it is taken unless that padding costs a wavefront per CU
   // (160 KiB of LDS: four wavefronts need <= 40 KiB each).
   using BV = StageDma<(L::VNODE + L::VEDGE) / 2>;
-  using BMflat = StageDma<(L::NODE + L::EDGE) / 2>;
-  using BMrows = StageDmaRows<(L::NODE + L::EDGE) / 2>;
+  using BMflat = StageDma<STG / 2>;
+  using BMrows = StageDmaRows<STG / 2>;
+  struct NoStream { // the A | B image of the unsplit kernel: none
+    static constexpr int INSTR = 0, BYTES = 0, ROW_BYTES = 0;
+  };
+  using BA = std::conditional_t<SPLIT, StageDmaRows<AB / 2>, NoStream>;
   static constexpr int SCR_BYTES_ = ((4 * 2 * N + N) * 8 + 1023) / 1024 * 1024;
   static constexpr int waves_per_cu(int bm_bytes) {
-    const int per_wave = 2 * (bm_bytes + BV::BYTES) + SCR_BYTES_;
+    const int per_wave = 2 * (bm_bytes + BA::BYTES + BV::BYTES) + SCR_BYTES_;
     const int w = 163840 / per_wave;
     return w > 4 ? 4 : w;
   }
 #ifdef SIP_QW16_DMA_FLAT
   using BM = BMflat;
 #else
-  using BM = std::conditional_t<waves_per_cu(BMrows::BYTES) >= waves_per_cu(BMflat::BYTES), BMrows, BMflat>;
+  using BM = std::conditional_t<SPLIT || waves_per_cu(BMrows::BYTES) >= waves_per_cu(BMflat::BYTES), BMrows, BMflat>;
 #endif
-  static constexpr int B_BYTES = BM::BYTES + BV::BYTES;
+  static constexpr int B_BYTES = BM::BYTES + BA::BYTES + BV::BYTES;
   // forward: A|B, gains, S|g|h of the child, delta of the child
   using FA = StageDma<(N * N + N * M) / 2>;
   using FG = StageDma<L::GAIN / 2>;
@@ -398,12 +407,16 @@ struct StagedCfg {
 // stage ahead of the arithmetic (needs N and M even: 16-byte pieces);
 // otherwise every lane loads its columns straight from global memory.
 // WPACK: spill only the lower triangle of the symmetric W.
-template <int N, int M, bool STAGED, bool WPACK>
+// SPLIT (staged, mode 0 only): stage i's A | B of problem p are the N * (N + M) scalars at
+// ab + p * ab_pstride + i * ab_sstride (column-major A then B, as in the packed layout) and the
+// mats stage block is [Q | delta | M | R].
+template <int N, int M, bool STAGED, bool WPACK, bool SPLIT = false>
 __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     const double *__restrict__ mats, const double *__restrict__ vecs,
     double *__restrict__ sol, double *__restrict__ gains,
     double *__restrict__ wsp, int *__restrict__ status, const long batch,
-    const int T, const int mode, double *__restrict__ gfac SIP_STAMP_ARG) {
+    const int T, const int mode, double *__restrict__ gfac,
+    const double *__restrict__ ab, const long ab_pstride, const long ab_sstride SIP_STAMP_ARG) {
   // mode 0: fused factor + solve.  mode 1 (split sip_lqr_factor): the backward sweep only, and the
   // LDL factors of the G matrices go to `gfac` ([problem][stage][Lt (M x M, column per lane) | 1/d
   // (M)]).  mode 2 (split sip_lqr_solve): no matrix work at all -- the affine sweep of
@@ -417,7 +430,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   static_assert(!(VDIST && STAGED), "N = 16 is instantiated without LDS staging");
   static_assert(M >= 1 && M <= 16, "");
   using L = ChainLayout<N, M>;
-  using C = StagedCfg<N, M, WPACK>;
+  using C = StagedCfg<N, M, WPACK, SPLIT>;
+  static_assert(!SPLIT || (STAGED && WPACK), "the split kernel is the staged one");
   unsigned long long ts_begin = 0, ts_term = 0, ts_bwd = 0, ts_root = 0,
                      ts_end = 0, ts_a = 0, ts_b = 0, acc_bwait = 0,
                      acc_fwait = 0;
@@ -427,7 +441,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   (void)seg, (void)seg_last;
   SIP_STAMP(ts_begin);
   static_assert(!STAGED || C::OK, "staged kernel needs even N and M");
-  constexpr int STG = L::NODE + L::EDGE;    // mats stage stride
+  constexpr int STG = C::STG;               // mats stage stride
+  // M^T and R inside a mats stage block (A | B sit between the node part and them unless SPLIT)
+  constexpr int OFF_M = L::NODE + (SPLIT ? 0 : N * N + N * M), OFF_R = OFF_M + N * M;
   constexpr int VSTG = L::VNODE + L::VEDGE; // vecs / sol stage stride
   constexpr int WSN = C::WSN;
   constexpr int WG = WPACK ? N * (N + 1) / 2 : N * N; // offset of g in a slot
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   const int cm = isM ? c : N - 1;   // clamped matrix column / row
   const int cu = c < M ? c : M - 1; // clamped control column / row
 
-  const long mats_len = (long)(T + 1) * L::NODE + (long)T * L::EDGE;
+  const long mats_len = (long)(T + 1) * L::NODE + (long)T * (STG - L::NODE);
   const long vecs_len = (long)(T + 1) * L::VNODE + (long)T * L::VEDGE;
   const long gains_len = (long)T * L::GAIN;
   const long ws_len = (long)(T + 1) * WSN;
@@ -617,16 +633,16 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   // stage block i of mats / vecs (global memory, or its LDS image).  Operands
   // are fetched one segment ahead of their use (the memory fences keep the
   // compiler from hoisting all ~140 registers of a stage to the top).
-  auto backward_edge = [&](const int i, auto nm, auto nv, NodeTail &nt) {
-    auto em = nm + L::NODE;
+  auto backward_edge = [&](const int i, auto nm, auto ea, auto nv, NodeTail &nt) { // ea: the stage's A | B
+
     // [F | g - v_c] = W [A | t]   (lqr.cpp:703 and :780-781)
     double F[N], Aaug[N], Bcol[N];
     double Hc[M], G[M], rinvG[M], H[M], K[M];
     {
-      auto msrc = isV ? nv + L::VNODE : em + (N * N + N * M + cm);
+      auto msrc = isV ? nv + L::VNODE : nm + (OFF_M + cm);
       sfor<0, M>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
-        G[j] = em[N * N + 2 * N * M + cu * M + j]; // column c of R
+        G[j] = nm[OFF_R + cu * M + j]; // column c of R
         // column c of M^T = row c of M; vector lane: r
         H[j] = isV ? msrc[j] : msrc[j * N];
       });
@@ -635,9 +651,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       // 16-byte aligned columns (N even): let the compiler use ds_read_b128
       typedef double d2 __attribute__((ext_vector_type(2)));
       typedef const __attribute__((address_space(3))) d2 lds_cd2;
-      lds_cd2 *a_src = (lds_cd2 *)(isV ? (lds_cdouble *)my_t : em + cm * N);
+      lds_cd2 *a_src = (lds_cd2 *)(isV ? (lds_cdouble *)my_t : ea + cm * N);
       lds_cd2 *f_src = (lds_cd2 *)(isV ? (lds_cdouble *)my_v : zeros);
-      lds_cd2 *b_src = (lds_cd2 *)(em + N * N + cu * N);
+      lds_cd2 *b_src = (lds_cd2 *)(ea + N * N + cu * N);
       static_assert(N % 2 == 0, "staged kernel: even N");
       sfor<0, N / 2>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
@@ -649,9 +665,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     } else {
       sfor<0, N>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
-        Aaug[k] = isV ? t[k] : em[cm * N + k];
+        Aaug[k] = isV ? t[k] : ea[cm * N + k];
         F[k] = isV ? vch[k] : 0.0;
-        Bcol[k] = em[N * N + cu * N + k];
+        Bcol[k] = ea[N * N + cu * N + k];
       });
     }
     rank1x<N, N, true>(F, W, Aaug);
@@ -764,17 +780,24 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   if (mode != 2) {
   // ---- terminal node (lqr.cpp:651-658 with no child edge) ----------------
   typename C::BM dma_bm;
+  typename C::BA dma_ba;
   typename C::BV dma_bv;
+  // stage i -> the LDS buffer at `buf`: [mats image | A|B image (SPLIT) | vecs image]
+  auto issue_backward = [&](const int i, lds_char *buf) {
+    dma_bm.template issue<SIP_LQR_NT_IN>((const char *)(mats + p0 * mats_len + (long)i * STG), buf, lane);
+    if constexpr (SPLIT)
+      dma_ba.template issue<SIP_LQR_NT_IN>((const char *)(ab + p0 * ab_pstride + (long)i * ab_sstride),
+                                           buf + C::BM::BYTES, lane);
+    dma_bv.template issue<SIP_LQR_NT_IN>((const char *)(vecs + p0 * vecs_len + (long)i * VSTG),
+                                         buf + C::BM::BYTES + C::BA::BYTES, lane);
+  };
   if constexpr (STAGED) {
     dma_bm.init(lane, (unsigned)(mats_len * 8), max_rel);
+    if constexpr (SPLIT)
+      dma_ba.init(lane, (unsigned)(ab_pstride * 8), max_rel);
     dma_bv.init(lane, (unsigned)(vecs_len * 8), max_rel);
-    if (T > 0) {
-      lds_char *buf = lds + ((T - 1) & 1) * C::B_BYTES;
-      dma_bm.template issue<SIP_LQR_NT_IN>((const char *)(mats + p0 * mats_len + (long)(T - 1) * STG),
-                   buf, lane);
-      dma_bv.template issue<SIP_LQR_NT_IN>((const char *)(vecs + p0 * vecs_len + (long)(T - 1) * VSTG),
-                   buf + C::BM::BYTES, lane);
-    }
+    if (T > 0)
+      issue_backward(T - 1, lds + ((T - 1) & 1) * C::B_BYTES);
   }
   {
     NodeTail nt;
@@ -813,26 +836,22 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       acc_bwait += ts_b - ts_a;
       SIP_SEG(0);
       if (i > 0) { // next stage streams into the other buffer meanwhile
-        lds_char *nbuf = lds + (PAR ^ 1) * C::B_BYTES;
-        dma_bm.template issue<SIP_LQR_NT_IN>((const char *)(mats + p0 * mats_len + (long)(i - 1) * STG),
-                     nbuf, lane);
-        dma_bv.template issue<SIP_LQR_NT_IN>(
-            (const char *)(vecs + p0 * vecs_len + (long)(i - 1) * VSTG),
-            nbuf + C::BM::BYTES, lane);
+        issue_backward(i - 1, lds + (PAR ^ 1) * C::B_BYTES);
         asm volatile("" ::: "memory"); // stores of this stage stay younger
       }
       lds_cdouble *nm = (lds_cdouble *)(buf + rr * C::BM::ROW_BYTES);
-      lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + rr * (VSTG * 8));
+      lds_cdouble *ea = SPLIT ? (lds_cdouble *)(buf + C::BM::BYTES + rr * C::BA::ROW_BYTES) : nm + L::NODE;
+      lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + C::BA::BYTES + rr * (VSTG * 8));
       SIP_SEG(1);
       NodeTail nt;
-      backward_edge(i, nm, nv, nt);
+      backward_edge(i, nm, ea, nv, nt);
       finish_node(i, nt);
     } else {
       const double *nm = pm + (long)i * STG;
       const double *nv = pv + (long)i * VSTG;
       SIP_SEG(1);
       NodeTail nt;
-      backward_edge(i, nm, nv, nt);
+      backward_edge(i, nm, nm + L::NODE, nv, nt);
       finish_node(i, nt);
     }
     SIP_SEG(9);
@@ -888,7 +907,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   }
   if (valid && c == 0)
     status[p] = stat;
-  } else {
+  } else if constexpr (!SPLIT) {
     // ---- mode 2: the affine sweep alone (lqr.cpp:738-796), vectors distributed over the lanes ----
     // Node step: t = c - delta o v; h = S D^{-1/2} t (spilled for the rollout); returns
     // W t = D^{-1/2} (I - S) D^{-1/2} t.
@@ -975,14 +994,15 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   typename C::FW dma_fw;
   typename C::FC dma_fd; // delta of the child node
   if constexpr (STAGED) {
-    dma_fa.init(lane, (unsigned)(mats_len * 8), max_rel);
+    dma_fa.init(lane, (unsigned)((SPLIT ? ab_pstride : mats_len) * 8), max_rel);
     dma_fg.init(lane, (unsigned)(gains_len * 8), max_rel);
     dma_fw.init(lane, (unsigned)(ws_len * 8), max_rel);
     dma_fd.init(lane, (unsigned)(mats_len * 8), max_rel);
   }
   auto issue_forward = [&](const int i, lds_char *buf) {
-    dma_fa.template issue<SIP_LQR_NT_FAB>((const char *)(mats + p0 * mats_len + (long)i * STG + L::NODE),
-                 buf, lane);
+    dma_fa.template issue<SIP_LQR_NT_FAB>(
+        (const char *)(SPLIT ? ab + p0 * ab_pstride + (long)i * ab_sstride : mats + p0 * mats_len + (long)i * STG + L::NODE),
+        buf, lane);
     dma_fg.template issue<SIP_LQR_NT_FSP>((const char *)(gains + p0 * gains_len + (long)i * L::GAIN),
                  buf + C::FA::BYTES, lane);
     dma_fw.template issue<SIP_LQR_NT_FSP>((const char *)(wsp + p0 * ws_len + (long)(i + 1) * WSN),

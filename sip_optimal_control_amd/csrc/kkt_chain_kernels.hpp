@@ -32,6 +32,9 @@ struct ChainKkt {
   // LDS plan (doubles, even): one whole stage of the model (condense) | every
   // Jacobian of a stage (recover) | constraint rows of a stage
   int lds_item, lds_tail, lds_rows;
+  // 1: the Riccati sweep reads ddyn_dx | ddyn_du in place (sip_lqr_factor_solve_split): the stage
+  // blocks of mats are [Q_mod | dyn_r2 | M_mod | R_mod] and nothing copies A | B (helpers.cpp:365-366)
+  int split;
 };
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -286,7 +289,7 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
     const int li = tid & 15, lg = tid >> 4;
     const int ncols = last ? n : n + m;
     const int nt = (ncols + 15) >> 4;
-    double *Qm = mats, *Am = mats + nn + n, *Bm = Am + nn, *Mm = Bm + nm, *Rm = Mm + nm;
+    double *Qm = mats, *Am = mats + nn + n, *Bm = Am + nn, *Mm = ck.split ? Am : Bm + nm, *Rm = Mm + nm;
     for (int ti = 0; ti < nt; ++ti) {
       for (int tj = 0; tj <= ti; ++tj) {
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -338,7 +341,7 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
     }
     if (tid < n)
       mats[nn + tid] = pre.d; // dyn_r2
-    if (!last) {
+    if (!last && !ck.split) {
       for (int k = tid; k < nn; k += TPB) // ddyn_dx, ddyn_du, :365-366
         Am[k] = eb[o_a + k];
       for (int k = tid; k < nm; k += TPB)
@@ -448,12 +451,20 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
     return condense_item<WITH_RHS>(ck, p, (int)(idx - p * (ck.T + 1)), model_all, r1_all, inv_all, mats_all, b_all,
                                    vecs_all);
   };
+  // split: the pieces of ddyn_dx | ddyn_du are not fetched (nothing here reads them; the Riccati
+  // sweep takes them from the arena itself) -- their lanes re-read the piece in front of them
+  const int ab_first = ck.split ? (ck.node_len + ck.n * ck.n + ck.n * ck.m + ck.m * ck.m) >> 1 : 0;
+  const int ab_end = ck.split ? ab_first + ((ck.n * ck.n + ck.n * ck.m) >> 1) : 0;
   auto image_load = [&](const CondenseItem &it, d2_t (&v)[PIPE_U]) {
     const d2_t *s2 = (const d2_t *)it.item;
     const int len2 = (it.node_len + it.edge_len) >> 1;
 #pragma unroll
-    for (int u = 0; u < PIPE_U; ++u)
-      v[u] = s2[min(tid + u * TPB, len2 - 1)];
+    for (int u = 0; u < PIPE_U; ++u) {
+      int q = min(tid + u * TPB, len2 - 1);
+      if (!it.last && q >= ab_first && q < ab_end)
+        q = ab_first - 1;
+      v[u] = s2[q];
+    }
   };
   CondenseItem cur = item_at(first);
   CondensePre pre;

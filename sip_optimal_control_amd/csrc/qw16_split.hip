@@ -1,0 +1,58 @@
+// qw16_split.hip -- the split form of the fused chain sweep (chain_qw16.hpp, SPLIT): the stage blocks of
+// `mats` carry [Q | delta | M | R] and the dynamics Jacobians A | B stream from where the model callback
+// left them.  Used by the Newton-KKT step (sip_kkt_factor_solve), whose condensation then neither reads
+// nor copies A | B (helpers.cpp:365-366 copies them into the LQR inputs).  Compiled in two slices
+// (-DSIP_QW16_SPLIT_SLICE=0 / 1) beside the other translation units.
+#include "qw16_launch.hpp"
+
+#ifndef SIP_QW16_SPLIT_SLICE
+#define SIP_QW16_SPLIT_SLICE 0
+#endif
+
+namespace sipamd {
+
+struct SplitEntry {
+  int n, m;
+  launch_split_t launch;
+};
+const SplitEntry *qw16_split_slice_1(int *count);
+
+#define QW16_SPLIT(N, M) {N, M, &launch_qw16_split<N, M>}
+// the staged shapes of the reference's Newton-KKT benchmark grid (newton_kkt_benchmark.cpp:264-273) and
+// the f1 shape of bench.py
+#if SIP_QW16_SPLIT_SLICE == 0
+
+namespace {
+const SplitEntry kSplit[] = {QW16_SPLIT(12, 4), QW16_SPLIT(4, 2), QW16_SPLIT(4, 4), QW16_SPLIT(6, 2)};
+}
+
+launch_split_t find_split_launch(int n, int m) {
+  for (const SplitEntry &e : kSplit)
+    if (e.n == n && e.m == m)
+      return e.launch;
+#if !defined(SIP_QW16_QUICK) && !defined(SIP_QW16_NO_EXTRA) // tools/ab_build.sh, tools/diag_build.sh link slice 0 alone
+  int count = 0;
+  const SplitEntry *more = qw16_split_slice_1(&count);
+  for (int k = 0; k < count; ++k)
+    if (more[k].n == n && more[k].m == m)
+      return more[k].launch;
+#endif
+  return nullptr;
+}
+
+long split_mats_stage(int n, int m) { return (long)n * n + n + (long)n * m + (long)m * m; }
+
+#else
+
+namespace {
+const SplitEntry kSplit[] = {QW16_SPLIT(6, 4), QW16_SPLIT(8, 2), QW16_SPLIT(8, 4), QW16_SPLIT(12, 2)};
+}
+
+const SplitEntry *qw16_split_slice_1(int *count) {
+  *count = (int)(sizeof(kSplit) / sizeof(kSplit[0]));
+  return kSplit;
+}
+
+#endif
+
+} // namespace sipamd

@@ -37,6 +37,9 @@ struct sip_kkt_plan {
   void *d_ints = nullptr, *d_longs = nullptr;
   sipamd::kkt::Meta meta{};
   bool chain_kernels = false; // uniform chain: arithmetic-offset kernels (kkt_chain_kernels.hpp)
+  // the fused step hands the Riccati sweep ddyn_dx | ddyn_du in the model arena instead of copying
+  // them into its inputs (sip_lqr_factor_solve_split); SIP_KKT_SPLIT=0 keeps the copy
+  bool chain_split = false;
   int chain_pipe = 0;         // > 0: stages per wavefront of the software-pipelined condensation
   sipamd::kkt::ChainKkt ck{};
   size_t lds_chain_condense = 0, lds_chain_recover = 0, lds_chain_apply = 0;
@@ -142,9 +145,17 @@ bool uniform_constraints(const sip_kkt_plan &p) {
 int even(int v) { return (v + 1) / 2 * 2; }
 
 // b != nullptr (fused factor+solve on the staged kernels): also builds q_mod, r_mod, c_mod.
+// split (chain kernels only): mats for sip_lqr_factor_solve_split -- no A | B in it.
 hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double *model, const double *w,
                            const double *r1, const double *r2, const double *r3, const double *b,
-                           hipStream_t s) {
+                           hipStream_t s, const bool split = false) {
+  sipamd::kkt::ChainKkt ck = p->ck;
+  if (split) {
+    const int n = ck.n, m = ck.m;
+    ck.split = 1;
+    ck.mats_stage = (n * n + n) + (n * m + m * m);
+    ck.mats_len = (long)(ck.T + 1) * (n * n + n) + (long)ck.T * (n * m + m * m);
+  }
   hipError_t e = sipamd::zero_async(r.reg, (size_t)p->batch * sizeof(int), s); // a kernel: stream_fill.hpp
   if (e != hipSuccess)
     return e;
@@ -158,18 +169,18 @@ hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double
       pipe ? (unsigned)(((long)p->batch * p->N + p->chain_pipe - 1) / p->chain_pipe) : 0u;
   if (pipe && b != nullptr)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_pipe_kernel<true>, dim3(pipe_grid), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch,
+                       p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch,
                        p->chain_pipe);
   else if (pipe)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_pipe_kernel<false>, dim3(pipe_grid), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, (const double *)nullptr,
+                       p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, (const double *)nullptr,
                        (double *)nullptr, (long)p->batch, p->chain_pipe);
   else if (p->chain_kernels && b != nullptr)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
+                       p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
   else if (p->chain_kernels)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_condense, s, p->ck, model, r1, r.inv, r.in0, (const double *)nullptr,
+                       p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, (const double *)nullptr,
                        (double *)nullptr, (long)p->batch);
   else if (p->staged && b != nullptr) // condensation and right-hand side from one staging of the model
     hipLaunchKernelGGL(sipamd::kkt::condense_staged_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
@@ -461,6 +472,7 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
     ck.model_len = p->model_len, ck.x_dim = p->x_dim, ck.y_dim = p->y_dim, ck.z_dim = p->z_dim;
     ck.mats_stage = (n * n + n) + (n * n + 2 * n * mm + mm * mm), ck.vecs_stage = 2 * n + mm;
     ck.mats_len = p->in0_len, ck.vecs_len = p->in1_len;
+    ck.split = 0;
     const int cgn = std::max(ck.cn + ck.gn, ck.cT + ck.gT), cge = ck.ce + ck.ge;
     ck.lds_item = even(n * n + cgn * n + ck.edge_len);
     ck.lds_tail = even(cgn * n + cge * (n + mm)); // recover: every Jacobian of a stage
@@ -484,8 +496,12 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
                       len_mid / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB &&
                       len_last / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB;
     p->chain_pipe = fits && per > 0 ? per : 0;
+    const char *se = std::getenv("SIP_KKT_SPLIT");
+    p->chain_split = E > 0 && sip_lqr_has_split(p->chain) == 1 && !(se != nullptr && se[0] == '0');
   }
   p->name += p->chain_kernels ? " + chain condensation" : p->staged ? " + staged condensation" : " + direct condensation";
+  if (p->chain_split)
+    p->name += " (A|B in place)";
 
   std::vector<int> ints;
   auto pi = [&](const std::vector<int> &v) {
@@ -654,12 +670,20 @@ int sip_kkt_factor_solve(const sip_kkt_plan *p, const double *d_model, const dou
   hipStream_t s = (hipStream_t)stream;
   const Regions r = regions(p, d_work);
   const bool fused_rhs = p->staged || p->chain_kernels;
-  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, fused_rhs ? d_b : nullptr, s);
+  // The dynamics Jacobians stay where the model callback left them when the sweep can read them
+  // in place (16-byte pieces: aligned arena, even block offsets and strides).
+  const long ab_off = (long)p->ck.node_len + p->ck.n * p->ck.n + p->ck.n * p->ck.m + p->ck.m * p->ck.m;
+  const long ab_stage = (long)p->ck.node_len + p->ck.edge_len;
+  const bool split = p->chain_split && fused_rhs && p->E > 0 &&
+                     ((((uintptr_t)d_model >> 3) | (uintptr_t)ab_off | (uintptr_t)ab_stage | (uintptr_t)p->ck.model_len) & 1) == 0;
+  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, fused_rhs ? d_b : nullptr, s, split);
   if (e == hipSuccess && !fused_rhs)
     e = launch_rhs(p, r, d_model, d_b, nullptr, s);
   if (e != hipSuccess)
     return report(e, "sip_kkt_factor_solve(condense)");
-  const int rc = sip_lqr_factor_solve(p->chain, r.in0, r.in1, r.out, r.gain, d_status, r.lqr, s);
+  const int rc = split ? sip_lqr_factor_solve_split(p->chain, r.in0, d_model + ab_off, p->ck.model_len, ab_stage, r.in1,
+                                                    r.out, r.gain, d_status, r.lqr, s)
+                       : sip_lqr_factor_solve(p->chain, r.in0, r.in1, r.out, r.gain, d_status, r.lqr, s);
   if (rc != SIP_LQR_OK)
     return rc;
   e = launch_merge(p, r, d_status, s);

@@ -619,6 +619,41 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
   return report(e, "sip_lqr_factor_solve(general)");
 }
 
+// The fused sweep with A | B read in place (chain_qw16.hpp, SPLIT; qw16_split.hip).
+int sip_lqr_has_split(const sip_lqr_plan *plan) {
+  return plan != nullptr && plan->dtype == SIP_LQR_F64 && !plan->padded && plan->launch_fs != nullptr &&
+                 plan->kernel_name != nullptr &&
+                 std::strstr(plan->kernel_name, "staged") != nullptr && sipamd::find_split_launch(plan->n, plan->m) != nullptr
+             ? 1
+             : 0;
+}
+
+int64_t sip_lqr_split_mats_len(const sip_lqr_plan *plan) {
+  if (plan == nullptr)
+    return 0;
+  const long node = (long)plan->n * plan->n + plan->n;
+  return (int64_t)(plan->T + 1) * node + (int64_t)plan->T * (sipamd::split_mats_stage(plan->n, plan->m) - node);
+}
+
+int sip_lqr_factor_solve_split(const sip_lqr_plan *plan, const void *d_mats, const void *d_ab,
+                               int64_t ab_problem_stride, int64_t ab_stage_stride, const void *d_vecs, void *d_sol,
+                               void *d_gains, int32_t *d_status, void *d_workspace, void *stream) {
+  if (plan == nullptr || !d_mats || !d_vecs || !d_sol || !d_status || !d_workspace ||
+      (plan->T > 0 && (!d_gains || !d_ab)) || ab_problem_stride < 0 || ab_stage_stride < 0)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
+  if (!sip_lqr_has_split(plan))
+    return SIP_LQR_ERR_UNSUPPORTED;
+  if (require_device(plan) != hipSuccess)
+    return report(hipErrorNoDevice, "sip_lqr_factor_solve_split");
+  sipamd::DeviceGuard on_device(plan->device);
+  if (on_device.err != hipSuccess)
+    return report(on_device.err, "sip_lqr_factor_solve_split(hipSetDevice)");
+  const sipamd::launch_split_t launch = sipamd::find_split_launch(plan->n, plan->m);
+  return report(launch(plan->batch, plan->T, d_mats, d_ab, (long)ab_problem_stride, (long)ab_stage_stride, d_vecs,
+                       d_sol, d_gains, d_status, d_workspace, (hipStream_t)stream),
+                "sip_lqr_factor_solve_split");
+}
+
 // Split entry points: always the general engine (its work arena holds the
 // reference's factor state W, G_factor, V, F_factor, sqrt_delta(_inv), v).
 int sip_lqr_factor(const sip_lqr_plan *plan, const void *d_mats, void *d_gains,

@@ -1,0 +1,86 @@
+"""sip_lqr_factor_solve_split: the fused chain sweep with the dynamics Jacobians read in place
+(helpers.cpp:365-366 copies ddyn_dx / ddyn_du into the LQR inputs; the Newton-KKT step hands them over where
+the model callback left them).  Same arithmetic as sip_lqr_factor_solve, so results must be bitwise equal
+to it on the same problems, and within 1e-9 of the CPU oracle like every fp64 chain kernel."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+SPLIT_SHAPES = [(12, 4), (4, 2), (4, 4), (6, 2), (6, 4), (8, 2), (8, 4), (12, 2)]
+
+
+def _rel(a, b):
+    scale = np.abs(b).max(axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    return (np.abs(a - b) / scale).max()
+
+
+def _problem(n, m, T, batch, seed):
+    from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
+    shape = ChainShape(n, m, T)
+    mats, vecs = synthetic.make_chain_batch(shape, batch, seed=seed, device="cuda:0", cross_term=0.01)
+    return BatchedChainLQR(n, m, T, batch, device="cuda:0"), mats, vecs
+
+
+@pytest.mark.parametrize("n,m", SPLIT_SHAPES)
+@pytest.mark.parametrize("T,batch", [(50, 37), (1, 5), (7, 4), (2, 1)])
+def test_split_equals_packed_and_oracle(oracle_lib, n, m, T, batch):
+    solver, mats, vecs = _problem(n, m, T, batch, seed=7 * n + m + T)
+    if not solver.has_split:
+        pytest.skip("no split kernel for this build (tools/ab_build.sh carries (12, 4) only)")
+    sol, gains, status = (t.clone() for t in solver.factor_solve(mats, vecs))
+    qmr, ab = solver.split_inputs(mats)
+    sol2, gains2, status2 = solver.factor_solve_split(qmr, ab, vecs)
+    torch.cuda.synchronize()
+    assert torch.equal(status, status2) and int(status.abs().sum()) == 0
+    assert torch.equal(sol, sol2) and torch.equal(gains, gains2)  # the same instructions on the same numbers
+    ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats.cpu().numpy(), vecs.cpu().numpy())
+    assert _rel(sol2.cpu().numpy(), ref_sol) <= TOL and _rel(gains2.cpu().numpy(), ref_gains) <= TOL
+
+
+def test_split_reads_strided_jacobians():
+    """A | B inside a larger per-stage record of a larger per-problem arena (what the model arena of the
+    Newton-KKT step looks like): strides come from the caller."""
+    n, m, T, batch = 12, 4, 50, 64
+    solver, mats, vecs = _problem(n, m, T, batch, seed=3)
+    if not solver.has_split:
+        pytest.skip("no split kernel")
+    qmr, ab = solver.split_inputs(mats)
+    arena = torch.full((batch, T + 3, 936), float("nan"), dtype=torch.float64, device="cuda:0")
+    view = arena[:, 1:T + 1, 520:520 + n * (n + m)]
+    view.copy_(ab)
+    sol, gains, status = (t.clone() for t in solver.factor_solve(mats, vecs))
+    sol2, gains2, status2 = solver.factor_solve_split(qmr, view, vecs)
+    torch.cuda.synchronize()
+    assert int(status2.abs().sum()) == 0
+    assert torch.equal(sol, sol2) and torch.equal(gains, gains2)
+
+
+def test_split_statuses():
+    """Factorization failures are reported as by the packed kernel (lqr.hpp:68-74)."""
+    n, m, T, batch = 12, 4, 20, 16
+    solver, mats, vecs = _problem(n, m, T, batch, seed=11)
+    if not solver.has_split:
+        pytest.skip("no split kernel")
+    stg = n * n + n + n * n + 2 * n * m + m * m
+    mats[3, 5 * stg + n * n + 2] = -1.0        # delta <= 0 at node 5
+    mats[7, 9 * stg: 9 * stg + n * n] *= -50.0  # indefinite Q at node 9
+    r = 11 * stg + n * n + n + n * n + 2 * n * m
+    mats[9, r: r + m * m] *= -80.0              # indefinite R at edge 11
+    _, _, status = solver.factor_solve(mats, vecs)
+    status = status.clone()
+    qmr, ab = solver.split_inputs(mats)
+    _, _, status2 = solver.factor_solve_split(qmr, ab, vecs)
+    torch.cuda.synchronize()
+    assert torch.equal(status, status2)
+    assert int(status[3]) == 1 and int(status[7]) != 0 and int(status[9]) != 0
+
+
+def test_unsupported_plans_say_so():
+    from sip_optimal_control_amd import BatchedChainLQR
+    assert not BatchedChainLQR(5, 3, 4, 2, device="cuda:0").has_split      # a direct kernel
+    assert not BatchedChainLQR(32, 8, 4, 2, dtype=torch.float32, device="cuda:0").has_split

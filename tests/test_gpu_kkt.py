@@ -203,13 +203,22 @@ def test_condensation_variants_agree_bitwise(monkeypatch):
     for variant in ("", "tables", "direct"):
         monkeypatch.setenv("SIP_KKT_VARIANT", variant)
         kkt = _make(dims, batch)
-        assert kkt.kernel_name.endswith({"": "chain condensation", "tables": "staged condensation",
-                                         "direct": "direct condensation"}[variant])
+        assert {"": "chain condensation", "tables": "staged condensation",
+                "direct": "direct condensation"}[variant] in kkt.kernel_name
         sol, st = kkt.factor_solve(*d)
         assert st.cpu().tolist() == [0] * batch
         kkt.factor(*d[:5])
         sols[variant] = (sol.clone(), kkt.solve(d[0], d[5]).clone())
     assert torch.equal(sols["tables"][0], sols["direct"][0]) and torch.equal(sols["tables"][1], sols["direct"][1])
+    # the fused step of a chain plan reads ddyn_dx | ddyn_du in place (sip_lqr_factor_solve_split) instead of
+    # copying them into the sweep's inputs (helpers.cpp:365-366): the same arithmetic on the same numbers
+    monkeypatch.setenv("SIP_KKT_VARIANT", "")
+    assert "(A|B in place)" in _make(dims, batch).kernel_name
+    monkeypatch.setenv("SIP_KKT_SPLIT", "0")
+    copying = _make(dims, batch)
+    assert "(A|B in place)" not in copying.kernel_name
+    assert torch.equal(copying.factor_solve(*d)[0], sols[""][0])
+    monkeypatch.delenv("SIP_KKT_SPLIT")
     for pair in (sols[""], sols["tables"]):  # fused and split entry points (the split solve is the
         tol = 1e-12 * pair[0].abs().amax(dim=1, keepdim=True)  # vector-only sweep: same to rounding)
         assert bool(((pair[0] - pair[1]).abs() <= tol).all())

@@ -9,6 +9,8 @@ NAME=$1; shift
 mkdir -p sip_optimal_control_amd/lib/diag build/ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -DSIP_QW16_NO_EXTRA -DSIP_QW16_QUICK "$@" \
   -save-temps=obj -c sip_optimal_control_amd/csrc/sip_lqr_amd.hip -o build/ab/$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/ab/$NAME.o build/obj/sip_lqr_tree/sip_lqr_tree.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -DSIP_QW16_QUICK "$@" \
+  -c sip_optimal_control_amd/csrc/qw16_split.hip -o build/ab/${NAME}_split.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/ab/$NAME.o build/ab/${NAME}_split.o build/obj/sip_lqr_tree/sip_lqr_tree.o \
   build/obj/sip_kkt_amd/sip_kkt_amd.o build/obj/tree_qw16/tree_qw16.o -o sip_optimal_control_amd/lib/diag/lib$NAME.so
 echo sip_optimal_control_amd/lib/diag/lib$NAME.so
