@@ -348,7 +348,45 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
         Bm[k] = eb[o_b + k];
     }
   }
-  if (WITH_RHS) { // q_mod, c_mod, r_mod (helpers.cpp:752-812)
+  if (WITH_RHS && !MATS && ncols_rhs > 1) {
+    // Several right-hand sides (the columns of J_theta, helpers.cpp:414-747) in TWO phases for all of
+    // them -- a loop over the columns exposed two barriers and two dependent global reads per column:
+    // (1) every column's weighted rows, wr[col][k] = w_k * rhs_col(k): all (col, k) pairs at once;
+    // (2) every (col, state row / control row) pair: one lane each, the same sums in the same order
+    //     as the single-column code below (bitwise the same numbers).
+    const int i = it.i, R = ck.lds_rows, nrows = it.nrows, per = n + m;
+    for (int e = tid; e < ncols_rhs * nrows; e += TPB) {
+      const int col = e / nrows, k = e - col * nrows;
+      const double *bc_y = it.b + col * b_col_stride + ck.x_dim, *bc_z = bc_y + ck.y_dim;
+      wr[col * R + k] = wl[k] * condense_rhs_row(it, k, bc_y, bc_z);
+    }
+    __syncthreads();
+    for (int e = tid; e < ncols_rhs * per; e += TPB) {
+      const int col = e / per, j = e - col * per;
+      if (last && j >= n)
+        continue;
+      const double *bc = it.b + col * b_col_stride, *bc_y = bc + ck.x_dim;
+      double *vc = it.vecs + col * vecs_col_stride;
+      const double *wr_n = wr + col * R, *wr_e = wr_n + c + g;
+      double acc = -bc[i * (n + m) + j];
+      if (j < n) {
+        const double dy = bc_y[it.y_dyn + j];
+        acc = dot_seq<true>(acc, Jc + c * j, wr_n, c);
+        acc = dot_seq<true>(acc, Jg + g * j, wr_n + c, g);
+        if (!last) {
+          acc = dot_seq<true>(acc, Jxc + ce * j, wr_e, ce);
+          acc = dot_seq<true>(acc, Jxg + ge * j, wr_e + ce, ge);
+        }
+        vc[j] = acc;
+        vc[n + j] = -dy;
+      } else {
+        const int d = j - n;
+        acc = dot_seq<true>(acc, Juc + ce * d, wr_e, ce);
+        acc = dot_seq<true>(acc, Jug + ge * d, wr_e + ce, ge);
+        vc[2 * n + d] = acc;
+      }
+    }
+  } else if (WITH_RHS) { // q_mod, c_mod, r_mod (helpers.cpp:752-812)
     const double *wr_n = wr, *wr_e = wr + c + g;
     const int i = it.i;
     for (int col = 0; col < ncols_rhs; ++col) {
@@ -396,7 +434,9 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
   // Jacobians of the stage are staged once for all columns.
   static_assert(MATS || WITH_RHS, "nothing to do");
   extern __shared__ double sm[];
-  double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows, *r1s = wr + ck.lds_rows;
+  // wr: one block of lds_rows per right-hand-side column when there are several (MATS = false)
+  double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows,
+         *r1s = wr + (long)(MATS || ncols < 1 ? 1 : ncols) * ck.lds_rows;
   const long p = blockIdx.x / (ck.T + 1);
   const int i = blockIdx.x - (unsigned)(p * (ck.T + 1));
   if (p >= batch || (!MATS && status != nullptr && status[p] != 0))
@@ -545,7 +585,48 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
     stage_copy_pair(jn, item + nn, (c + g) * n, je, item + nn + (c + g) * n + 2 * nn + 2 * nm + m * m,
                     (ce + ge) * (n + m), tid);
   const double *Jxc = je, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
-  for (int col = 0; col < ncols; ++col) { // ncols > 1: the columns of K^-1 J_theta, Jacobians staged once
+  if (ncols > 1) {
+    // The columns of K^-1 J_theta (helpers.cpp:414-747) in two phases for all of them, not a loop
+    // over the columns (two barriers and two dependent global reads per column): (1) x_i | u_i of
+    // every column into LDS (xs: one block of n + m per column) and out to sol; (2) every
+    // (column, constraint row) pair, one lane each -- the sums of the single-column code.
+    const int per = n + m, rows_n = c + g, rows = rows_n + ce + ge;
+    for (int e = tid; e < ncols * per; e += TPB) {
+      const int col = e / per, j = e - col * per;
+      if (last && j >= n)
+        continue;
+      const double *ls = lqr_sol_all + col * lqr_col_stride + p * ck.vecs_len + (long)i * ck.vecs_stage; // x_i | y_i | u_i
+      double *sol = sol_all + col * sol_col_stride + p * kkt, *sol_y = sol + ck.x_dim;
+      const double v = j < n ? ls[j] : ls[2 * n + (j - n)];
+      xs[col * per + j] = v; // us of a column sits behind its xs
+      sol[i * (n + m) + j] = v;
+      if (j < n)
+        sol_y[y_dyn + j] = ls[n + j];
+    }
+    __syncthreads(); // x_i | u_i of the columns and the Jacobians are in LDS
+    for (int e = tid; e < ncols * rows; e += TPB) {
+      const int col = e / rows, k = e - col * rows;
+      const double *b_y = b_all + col * b_col_stride + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
+      double *sol_y = sol_all + col * sol_col_stride + p * kkt + ck.x_dim, *sol_z = sol_y + ck.y_dim;
+      const double *xc = xs + col * per, *uc = xc + n;
+      if (k < c) {
+        sol_y[y_nc + k] = (row_dot(jn, k, c, n, xc) - b_y[y_nc + k]) * yinv[y_nc + k];
+      } else if (k < rows_n) {
+        const int kk = k - c;
+        sol_z[z_n + kk] = (row_dot(jn + c * n, kk, g, n, xc) - b_z[z_n + kk]) * zinv[z_n + kk];
+      } else if (k < rows_n + ce) {
+        const int kk = k - rows_n;
+        const double jx = row_dot(Jxc, kk, ce, n, xc), ju = row_dot(Juc, kk, ce, m, uc);
+        sol_y[y_ec + kk] = ((jx + ju) - b_y[y_ec + kk]) * yinv[y_ec + kk];
+      } else {
+        const int kk = k - rows_n - ce;
+        const double jx = row_dot(Jxg, kk, ge, n, xc), ju = row_dot(Jug, kk, ge, m, uc);
+        sol_z[z_e + kk] = ((jx + ju) - b_z[z_e + kk]) * zinv[z_e + kk];
+      }
+    }
+    return;
+  }
+  for (int col = 0; col < ncols; ++col) {
     const double *b_y = b_all + col * b_col_stride + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
     const double *ls = lqr_sol_all + col * lqr_col_stride + p * ck.vecs_len + (long)i * ck.vecs_stage; // x_i | y_i | u_i
     double *sol = sol_all + col * sol_col_stride + p * kkt, *sol_y = sol + ck.x_dim, *sol_z = sol_y + ck.y_dim;

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -856,10 +857,16 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
     // Jacobians, one Riccati solve per column, the multipliers of all columns from one staging
     const Regions r = regions(p, d_work);
     const long colJ = (long)p->batch * skkt, colV = (long)p->batch * p->in1_len;
-    hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false>), dim3(node_grid(p)),
-                       dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, p->ck, d_model, (const double *)nullptr,
-                       r.inv, r.in0, (const double *)t.J, t.vecs_cols, (long)p->batch, (const int32_t *)d_status,
-                       th, colJ, colV);
+    // (LDS: one block of weighted rows per column; as many columns per launch as 64 KiB hold)
+    const size_t rhs_col_lds = sizeof(double) * (size_t)p->ck.lds_rows;
+    const int rhs_cols = 1 + (int)std::min<size_t>((size_t)(th - 1), (64 * 1024 - p->lds_chain_condense) / std::max<size_t>(rhs_col_lds, 1));
+    for (int c0 = 0; c0 < th; c0 += rhs_cols) {
+      const int nc = std::min(rhs_cols, th - c0);
+      hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false>), dim3(node_grid(p)),
+                         dim3(sipamd::kkt::TPB), p->lds_chain_condense + rhs_col_lds * (size_t)(nc - 1), s, p->ck,
+                         d_model, (const double *)nullptr, r.inv, r.in0, (const double *)t.J + (size_t)c0 * colJ,
+                         t.vecs_cols + (size_t)c0 * colV, (long)p->batch, (const int32_t *)d_status, nc, colJ, colV);
+    }
     if ((e = hipGetLastError()) != hipSuccess)
       return report(e, "sip_kkt_factor_theta(rhs)");
     // all columns through one backward / forward sweep where the shape has the multi-rhs kernel
@@ -867,10 +874,16 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
     rc = sip_lqr_solve_multi(p->chain, r.in0, t.vecs_cols, t.lsol_cols, th, r.gain, r.lqr, t.cws, s);
     if (rc != SIP_LQR_OK)
       return rc;
-    hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_recover, s, p->ck, d_model, (const double *)t.J, r.inv,
-                       (const double *)t.lsol_cols, t.KJ, (const int32_t *)d_status, (long)p->batch, th, colJ, colV,
-                       colJ);
+    // (LDS: x_i | u_i of every column of a launch)
+    const size_t rec_col_lds = sizeof(double) * (size_t)(p->ck.n + p->ck.m);
+    const int rec_cols = 1 + (int)std::min<size_t>((size_t)(th - 1), (64 * 1024 - p->lds_chain_recover) / rec_col_lds);
+    for (int c0 = 0; c0 < th; c0 += rec_cols) {
+      const int nc = std::min(rec_cols, th - c0);
+      hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                         p->lds_chain_recover + rec_col_lds * (size_t)(nc - 1), s, p->ck, d_model,
+                         (const double *)t.J + (size_t)c0 * colJ, r.inv, (const double *)t.lsol_cols + (size_t)c0 * colV,
+                         t.KJ + (size_t)c0 * colJ, (const int32_t *)d_status, (long)p->batch, nc, colJ, colV, colJ);
+    }
     if ((e = hipGetLastError()) != hipSuccess)
       return report(e, "sip_kkt_factor_theta(recover)");
   } else {
