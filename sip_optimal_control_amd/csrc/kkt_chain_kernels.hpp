@@ -355,35 +355,59 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
     // (2) every (col, state row / control row) pair: one lane each, the same sums in the same order
     //     as the single-column code below (bitwise the same numbers).
     const int i = it.i, R = ck.lds_rows, nrows = it.nrows, per = n + m;
-    for (int e = tid; e < ncols_rhs * nrows; e += TPB) {
-      const int col = e / nrows, k = e - col * nrows;
-      const double *bc_y = it.b + col * b_col_stride + ck.x_dim, *bc_z = bc_y + ck.y_dim;
-      wr[col * R + k] = wl[k] * condense_rhs_row(it, k, bc_y, bc_z);
+    constexpr int U = 4; // pairs per lane and trip: their global reads are all requested first
+    for (int e0 = tid; e0 < ncols_rhs * nrows; e0 += U * TPB) {
+      double bv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * TPB, col = e / nrows, k = e - col * nrows;
+        const double *bc_y = it.b + col * b_col_stride + ck.x_dim, *bc_z = bc_y + ck.y_dim;
+        bv[u] = e < ncols_rhs * nrows ? condense_rhs_row(it, k, bc_y, bc_z) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * TPB, col = e / nrows, k = e - col * nrows;
+        if (e < ncols_rhs * nrows)
+          wr[col * R + k] = wl[k] * bv[u];
+      }
     }
     __syncthreads();
-    for (int e = tid; e < ncols_rhs * per; e += TPB) {
-      const int col = e / per, j = e - col * per;
-      if (last && j >= n)
-        continue;
-      const double *bc = it.b + col * b_col_stride, *bc_y = bc + ck.x_dim;
-      double *vc = it.vecs + col * vecs_col_stride;
-      const double *wr_n = wr + col * R, *wr_e = wr_n + c + g;
-      double acc = -bc[i * (n + m) + j];
-      if (j < n) {
-        const double dy = bc_y[it.y_dyn + j];
-        acc = dot_seq<true>(acc, Jc + c * j, wr_n, c);
-        acc = dot_seq<true>(acc, Jg + g * j, wr_n + c, g);
-        if (!last) {
-          acc = dot_seq<true>(acc, Jxc + ce * j, wr_e, ce);
-          acc = dot_seq<true>(acc, Jxg + ge * j, wr_e + ce, ge);
+    for (int e0 = tid; e0 < ncols_rhs * per; e0 += 2 * TPB) {
+      double q0[2], dy[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * TPB, col = e / per, j = e - col * per;
+        q0[u] = dy[u] = 0.0;
+        if (e < ncols_rhs * per && !(last && j >= n)) {
+          const double *bc = it.b + col * b_col_stride, *bc_y = bc + ck.x_dim;
+          q0[u] = bc[i * (n + m) + j];
+          if (j < n)
+            dy[u] = bc_y[it.y_dyn + j];
         }
-        vc[j] = acc;
-        vc[n + j] = -dy;
-      } else {
-        const int d = j - n;
-        acc = dot_seq<true>(acc, Juc + ce * d, wr_e, ce);
-        acc = dot_seq<true>(acc, Jug + ge * d, wr_e + ce, ge);
-        vc[2 * n + d] = acc;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * TPB, col = e / per, j = e - col * per;
+        if (e >= ncols_rhs * per || (last && j >= n))
+          continue;
+        double *vc = it.vecs + col * vecs_col_stride;
+        const double *wr_n = wr + col * R, *wr_e = wr_n + c + g;
+        double acc = -q0[u];
+        if (j < n) {
+          acc = dot_seq<true>(acc, Jc + c * j, wr_n, c);
+          acc = dot_seq<true>(acc, Jg + g * j, wr_n + c, g);
+          if (!last) {
+            acc = dot_seq<true>(acc, Jxc + ce * j, wr_e, ce);
+            acc = dot_seq<true>(acc, Jxg + ge * j, wr_e + ce, ge);
+          }
+          vc[j] = acc;
+          vc[n + j] = -dy[u];
+        } else {
+          const int d = j - n;
+          acc = dot_seq<true>(acc, Juc + ce * d, wr_e, ce);
+          acc = dot_seq<true>(acc, Jug + ge * d, wr_e + ce, ge);
+          vc[2 * n + d] = acc;
+        }
       }
     }
   } else if (WITH_RHS) { // q_mod, c_mod, r_mod (helpers.cpp:752-812)
@@ -591,37 +615,76 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
     // every column into LDS (xs: one block of n + m per column) and out to sol; (2) every
     // (column, constraint row) pair, one lane each -- the sums of the single-column code.
     const int per = n + m, rows_n = c + g, rows = rows_n + ce + ge;
-    for (int e = tid; e < ncols * per; e += TPB) {
-      const int col = e / per, j = e - col * per;
-      if (last && j >= n)
-        continue;
-      const double *ls = lqr_sol_all + col * lqr_col_stride + p * ck.vecs_len + (long)i * ck.vecs_stage; // x_i | y_i | u_i
-      double *sol = sol_all + col * sol_col_stride + p * kkt, *sol_y = sol + ck.x_dim;
-      const double v = j < n ? ls[j] : ls[2 * n + (j - n)];
-      xs[col * per + j] = v; // us of a column sits behind its xs
-      sol[i * (n + m) + j] = v;
-      if (j < n)
-        sol_y[y_dyn + j] = ls[n + j];
+    for (int e0 = tid; e0 < ncols * per; e0 += 2 * TPB) { // two pairs per lane and trip, loads first
+      double v0[2], v1[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * TPB, col = e / per, j = e - col * per;
+        v0[u] = v1[u] = 0.0;
+        if (e < ncols * per && !(last && j >= n)) {
+          const double *ls = lqr_sol_all + col * lqr_col_stride + p * ck.vecs_len + (long)i * ck.vecs_stage; // x_i | y_i | u_i
+          v0[u] = j < n ? ls[j] : ls[2 * n + (j - n)];
+          if (j < n)
+            v1[u] = ls[n + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * TPB, col = e / per, j = e - col * per;
+        if (e >= ncols * per || (last && j >= n))
+          continue;
+        double *sol = sol_all + col * sol_col_stride + p * kkt, *sol_y = sol + ck.x_dim;
+        xs[col * per + j] = v0[u]; // us of a column sits behind its xs
+        sol[i * (n + m) + j] = v0[u];
+        if (j < n)
+          sol_y[y_dyn + j] = v1[u];
+      }
     }
     __syncthreads(); // x_i | u_i of the columns and the Jacobians are in LDS
-    for (int e = tid; e < ncols * rows; e += TPB) {
-      const int col = e / rows, k = e - col * rows;
-      const double *b_y = b_all + col * b_col_stride + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
-      double *sol_y = sol_all + col * sol_col_stride + p * kkt + ck.x_dim, *sol_z = sol_y + ck.y_dim;
-      const double *xc = xs + col * per, *uc = xc + n;
-      if (k < c) {
-        sol_y[y_nc + k] = (row_dot(jn, k, c, n, xc) - b_y[y_nc + k]) * yinv[y_nc + k];
-      } else if (k < rows_n) {
-        const int kk = k - c;
-        sol_z[z_n + kk] = (row_dot(jn + c * n, kk, g, n, xc) - b_z[z_n + kk]) * zinv[z_n + kk];
-      } else if (k < rows_n + ce) {
-        const int kk = k - rows_n;
-        const double jx = row_dot(Jxc, kk, ce, n, xc), ju = row_dot(Juc, kk, ce, m, uc);
-        sol_y[y_ec + kk] = ((jx + ju) - b_y[y_ec + kk]) * yinv[y_ec + kk];
-      } else {
-        const int kk = k - rows_n - ce;
-        const double jx = row_dot(Jxg, kk, ge, n, xc), ju = row_dot(Jug, kk, ge, m, uc);
-        sol_z[z_e + kk] = ((jx + ju) - b_z[z_e + kk]) * zinv[z_e + kk];
+    // four pairs per lane and trip: their right-hand-side entries and weights are all requested
+    // before the first sum starts (one memory round trip per trip, not one per pair)
+    constexpr int U = 4;
+    for (int e0 = tid; e0 < ncols * rows; e0 += U * TPB) {
+      double bv[U], wv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * TPB;
+        bv[u] = wv[u] = 0.0;
+        if (e < ncols * rows) {
+          const int col = e / rows, k = e - col * rows;
+          const double *b_y = b_all + col * b_col_stride + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
+          if (k < c)
+            bv[u] = b_y[y_nc + k], wv[u] = yinv[y_nc + k];
+          else if (k < rows_n)
+            bv[u] = b_z[z_n + (k - c)], wv[u] = zinv[z_n + (k - c)];
+          else if (k < rows_n + ce)
+            bv[u] = b_y[y_ec + (k - rows_n)], wv[u] = yinv[y_ec + (k - rows_n)];
+          else
+            bv[u] = b_z[z_e + (k - rows_n - ce)], wv[u] = zinv[z_e + (k - rows_n - ce)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * TPB;
+        if (e >= ncols * rows)
+          break;
+        const int col = e / rows, k = e - col * rows;
+        double *sol_y = sol_all + col * sol_col_stride + p * kkt + ck.x_dim, *sol_z = sol_y + ck.y_dim;
+        const double *xc = xs + col * per, *uc = xc + n;
+        if (k < c) {
+          sol_y[y_nc + k] = (row_dot(jn, k, c, n, xc) - bv[u]) * wv[u];
+        } else if (k < rows_n) {
+          const int kk = k - c;
+          sol_z[z_n + kk] = (row_dot(jn + c * n, kk, g, n, xc) - bv[u]) * wv[u];
+        } else if (k < rows_n + ce) {
+          const int kk = k - rows_n;
+          const double jx = row_dot(Jxc, kk, ce, n, xc), ju = row_dot(Juc, kk, ce, m, uc);
+          sol_y[y_ec + kk] = ((jx + ju) - bv[u]) * wv[u];
+        } else {
+          const int kk = k - rows_n - ce;
+          const double jx = row_dot(Jxg, kk, ge, n, xc), ju = row_dot(Jug, kk, ge, m, uc);
+          sol_z[z_e + kk] = ((jx + ju) - bv[u]) * wv[u];
+        }
       }
     }
     return;
