@@ -558,7 +558,10 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
   }
 }
 
-// x, u, y scatter + multipliers of node i and edge i (helpers.cpp:817-892).
+// x, u, y scatter + multipliers of node i and edge i (helpers.cpp:817-892).  COLS: the instantiation
+// for several columns per launch (the two-phase form below) -- a kernel of its own so that the
+// single-column one keeps its 58 registers and eight wavefronts per SIMD.
+template <bool COLS = false>
 __global__ void __launch_bounds__(TPB)
 recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, const double *__restrict__ b_all,
                      const double *__restrict__ inv_all, const double *__restrict__ lqr_sol_all,
@@ -609,7 +612,7 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
     stage_copy_pair(jn, item + nn, (c + g) * n, je, item + nn + (c + g) * n + 2 * nn + 2 * nm + m * m,
                     (ce + ge) * (n + m), tid);
   const double *Jxc = je, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
-  if (ncols > 1) {
+  if constexpr (COLS) {
     // The columns of K^-1 J_theta (helpers.cpp:414-747) in two phases for all of them, not a loop
     // over the columns (two barriers and two dependent global reads per column): (1) x_i | u_i of
     // every column into LDS (xs: one block of n + m per column) and out to sol; (2) every
@@ -641,9 +644,9 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
       }
     }
     __syncthreads(); // x_i | u_i of the columns and the Jacobians are in LDS
-    // four pairs per lane and trip: their right-hand-side entries and weights are all requested
+    // two pairs per lane and trip: their right-hand-side entries and weights are all requested
     // before the first sum starts (one memory round trip per trip, not one per pair)
-    constexpr int U = 4;
+    constexpr int U = 2;
     for (int e0 = tid; e0 < ncols * rows; e0 += U * TPB) {
       double bv[U], wv[U];
 #pragma unroll
@@ -688,7 +691,7 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
       }
     }
     return;
-  }
+  } else {
   for (int col = 0; col < ncols; ++col) {
     const double *b_y = b_all + col * b_col_stride + p * kkt + ck.x_dim, *b_z = b_y + ck.y_dim;
     const double *ls = lqr_sol_all + col * lqr_col_stride + p * ck.vecs_len + (long)i * ck.vecs_stage; // x_i | y_i | u_i
@@ -726,6 +729,7 @@ recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, co
       }
     }
   }
+  } // !COLS
 }
 
 // y += K x (helpers.cpp:953-1368), or the selected blocks of it (ApplyIO::parts: the five operators

@@ -220,7 +220,7 @@ hipError_t launch_rhs(const sip_kkt_plan *p, const Regions &r, const double *mod
 hipError_t launch_recover(const sip_kkt_plan *p, const Regions &r, const double *model, const double *b,
                           double *sol, const int32_t *status, hipStream_t s) {
   if (p->chain_kernels)
-    hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+    hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
                        p->lds_chain_recover, s, p->ck, model, b, r.inv, r.out, sol, status, (long)p->batch);
   else if (p->staged)
     hipLaunchKernelGGL(sipamd::kkt::recover_staged_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
@@ -879,10 +879,16 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
     const int rec_cols = 1 + (int)std::min<size_t>((size_t)(th - 1), (64 * 1024 - p->lds_chain_recover) / rec_col_lds);
     for (int c0 = 0; c0 < th; c0 += rec_cols) {
       const int nc = std::min(rec_cols, th - c0);
-      hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                         p->lds_chain_recover + rec_col_lds * (size_t)(nc - 1), s, p->ck, d_model,
-                         (const double *)t.J + (size_t)c0 * colJ, r.inv, (const double *)t.lsol_cols + (size_t)c0 * colV,
-                         t.KJ + (size_t)c0 * colJ, (const int32_t *)d_status, (long)p->batch, nc, colJ, colV, colJ);
+      if (nc > 1)
+        hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                           p->lds_chain_recover + rec_col_lds * (size_t)(nc - 1), s, p->ck, d_model,
+                           (const double *)t.J + (size_t)c0 * colJ, r.inv, (const double *)t.lsol_cols + (size_t)c0 * colV,
+                           t.KJ + (size_t)c0 * colJ, (const int32_t *)d_status, (long)p->batch, nc, colJ, colV, colJ);
+      else
+        hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                           p->lds_chain_recover, s, p->ck, d_model, (const double *)t.J + (size_t)c0 * colJ, r.inv,
+                           (const double *)t.lsol_cols + (size_t)c0 * colV, t.KJ + (size_t)c0 * colJ,
+                           (const int32_t *)d_status, (long)p->batch, 1, colJ, colV, colJ);
     }
     if ((e = hipGetLastError()) != hipSuccess)
       return report(e, "sip_kkt_factor_theta(recover)");
