@@ -123,6 +123,35 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
     return (on && idx < len) ? ld : fill;
   };
 
+  // L2 prefetch of a span of `len` scalars at `span` (this row's problem): every lane pulls one
+  // dword of a different 64-byte line into a 256-byte LDS sink by LDS-DMA -- no destination
+  // registers, nothing ever waits for it -- so the demand loads of the NEXT step find their lines in
+  // the XCD's L2 instead of paying an HBM round trip at the top of every step.  LINES16: how many
+  // groups of 16 lines (1 KiB per problem) the span may need.
+  // (Not in the largest class: (15, 8) fills the register file -- 256 VGPRs + 240 AGPRs -- and the
+  // prefetch's few extra live values would push it into scratch.)
+  __shared__ unsigned prefetch_sink[64];
+#ifdef SIP_TREE_NO_PREFETCH
+  constexpr bool kPrefetch = false;
+#else
+  constexpr bool kPrefetch = N * (N + 2 * M) <= 400;
+#endif
+  auto prefetch = [&](const double *span, const long len, auto groups) {
+    if constexpr (kPrefetch) {
+    const long last = len > 0 ? (len - 1) * 8 : 0; // byte offset of the span's last scalar
+    const char *b = (const char *)(len > 0 ? span : in);
+    sfor<0, decltype(groups)::value>([&](auto gg) {
+      long off = (long)(decltype(gg)::value * 16 + c) * 64;
+      off = off < last ? off : last;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b + off),
+                                       (__attribute__((address_space(3))) void *)prefetch_sink, 4, 0, 0);
+    });
+    }
+  };
+  using G1 = std::integral_constant<int, 1>;
+  using G2 = std::integral_constant<int, (N * (N + 2 * M) + M * M + M + 127) / 128>; // an edge block A | B | M | R | r
+  using GW = std::integral_constant<int, (L::WS + 127) / 128>;                       // a spill slot
+
   int stat = 0;
   double W[N], V[N], tv[N]; // W / tv: of the node finished last; V: accumulator of the current parent
   double Vc[N];             // [V | v] of the node finished last (its vector lane: v), for TS_CHILD_LIVE
@@ -256,14 +285,29 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
       asm volatile("" ::: "memory");
     }
   };
-  // (Requesting the blocks of step s + 1 before the arithmetic of step s -- two alternating register
-  // sets -- was measured and did not pay: 0.87 against 0.84 ms on the heterogeneous chain of the
-  // reference's benchmark family; the steps are bound by the store -> load round trips of the spill and
-  // by the serial pivot chains, not by the latency of the read-only inputs.)
+  // (Requesting the blocks of step s + 1 into a second REGISTER set before the arithmetic of step s did
+  // not pay -- 0.87 against 0.84 ms on the heterogeneous chain of the reference's benchmark family: the
+  // kernel is at 256 VGPRs + AGPR copies already -- and neither did requesting a non-live child's spill
+  // slot with the step's other inputs (+40 registers: 0.84 against 0.78).  The register-free L2 prefetch
+  // below does: 0.835 -> 0.775 ms there, 0.96 -> 0.89 / 0.925 -> 0.86 ms on the two trees.)
+  // (the record of step s + 1 is read during step s: its scalar loads are not waited for at the top of a step)
+  TreeStep nx = ts.backward[0];
   for (int s = 0; s < ts.n_backward; ++s) {
-    const TreeStep st = ts.backward[s];
+    const TreeStep st = kPrefetch ? nx : ts.backward[s];
     Pre pre;
     fetch(st, pre);
+    if (kPrefetch && s + 1 < ts.n_backward) { // the read-only inputs of the next step, on their way to L2 meanwhile
+      nx = ts.backward[s + 1];
+      if (nx.kind == 0)
+        prefetch(in + nx.oA, (long)nx.nc * (nx.n + nx.m) + (long)nx.n * nx.m + (long)nx.m * nx.m + nx.m, G2{});
+      // node block [Q | q | c | delta] of the step's node (an edge step needs it when it opens the node;
+      // its child's delta sits in a block an earlier step already read)
+      if (nx.kind == 1 || (nx.flags & TS_LOAD_V))
+        prefetch(in + nx.oQ, (long)nx.n * (nx.n + 3), G2{});
+      // a child finished longer ago comes back from the spill (its S | g | h | t | v slot)
+      if (nx.kind == 0 && !(nx.flags & TS_CHILD_LIVE))
+        prefetch(pw + (long)nx.child * L::WS, L::WS, GW{});
+    }
     backward_step(st, pre);
   }
   // root (the last node step): g = v + W (c - delta o v)  (lqr.cpp:798-819)
@@ -295,9 +339,18 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
     }
     xlast = c < n ? x0 : 0.0;
   }
+  if (ts.n_forward > 0)
+    nx = ts.forward[0];
   for (int s = 0; s < ts.n_forward; ++s) {
-    const TreeStep st = ts.forward[s];
+    const TreeStep st = kPrefetch ? nx : ts.forward[s];
     const int e = st.edge, n = st.n, nc = st.nc, m = st.m;
+    if (kPrefetch && s + 1 < ts.n_forward) { // A | B, gains, spill slot and delta of the next edge / child
+      nx = ts.forward[s + 1];
+      prefetch(in + nx.oA, (long)nx.nc * (nx.n + nx.m), G2{});
+      prefetch(pg + (long)nx.edge * L::GAIN, L::GAIN, G1{});
+      prefetch(pw + (long)nx.child * L::WS, L::WS, GW{});
+      prefetch(in + nx.odc, nx.nc, G1{});
+    }
     double x;
     if (st.flags & TS_CHILD_LIVE) {
       x = xlast;
