@@ -84,7 +84,9 @@ using sipamd::KernelEntry;
     sipamd::mf32::Layout<M>::WSN, &launch_mf32<M> }
 
 const KernelEntry kKernels[] = {
-#ifdef SIP_QW16_QUICK // tools/ab_build.sh: the C3 kernel alone, for A/B timing of kernel variants
+#if defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_C4) // tools/ab_build.sh: one kernel alone, for A/B timing
+    MF32(8),
+#elif defined(SIP_QW16_QUICK)
     QW16_STAGED(12, 4),
 #else
     MF32(8), QW16_STAGED_MR(12, 4), QW16_STAGED_MR(4, 2), QW16_DIRECT(12, 4),
