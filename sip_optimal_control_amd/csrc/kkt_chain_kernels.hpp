@@ -269,7 +269,8 @@ template <bool WITH_RHS, bool MATS>
 __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const CondenseItem &it, const int tid,
                                                  const CondensePre &pre, const double *buf, const double *wl,
                                                  double *wr, const double *r1s, const int ncols_rhs,
-                                                 const long b_col_stride, const long vecs_col_stride) {
+                                                 const long b_col_stride, const long vecs_col_stride,
+                                                 double *obuf = nullptr) {
   const int n = ck.n, m = ck.m, nn = n * n, nm = n * m;
   const bool last = it.last;
   const int c = it.c, g = it.g, ce = it.ce, ge = it.ge;
@@ -277,7 +278,10 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
   const double *eb = buf + it.node_len; // edge item
   const int o_m = nn, o_r = o_m + nm, o_a = o_r + m * m, o_b = o_a + nn, o_j = o_b + nm;
   const double *Jxc = eb + o_j, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
-  double *mats = it.mats;
+  // MATS: the stage block of mats is assembled in LDS (obuf) and leaves as one coalesced copy -- the tile
+  // epilogue below scatters single scalars (lane l of a tile row writes column l: 96-byte strides), which as
+  // global stores were one 8-byte L2 transaction per lane and element
+  double *mats = MATS ? obuf : it.mats;
 
   if (MATS)
   // ---- Q_mod, M_mod, R_mod (helpers.cpp:299-361) ----
@@ -347,6 +351,12 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
       for (int k = tid; k < nm; k += TPB)
         Bm[k] = eb[o_b + k];
     }
+  }
+  if (MATS) {
+    __syncthreads();
+    const int len = last ? nn + n : ck.mats_stage;
+    for (int k = tid; k < len; k += TPB)
+      it.mats[k] = obuf[k];
   }
   if (WITH_RHS && !MATS && ncols_rhs > 1) {
     // Several right-hand sides (the columns of J_theta, helpers.cpp:414-747) in TWO phases for all of
@@ -461,6 +471,7 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
   // wr: one block of lds_rows per right-hand-side column when there are several (MATS = false)
   double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows,
          *r1s = wr + (long)(MATS || ncols < 1 ? 1 : ncols) * ck.lds_rows;
+  double *obuf = r1s + ((ck.n + ck.m + 1) & ~1); // MATS: the stage block of mats before it leaves
   const long p = blockIdx.x / (ck.T + 1);
   const int i = blockIdx.x - (unsigned)(p * (ck.T + 1));
   if (p >= batch || (!MATS && status != nullptr && status[p] != 0))
@@ -485,7 +496,7 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
   }
   condense_commit<WITH_RHS, MATS>(ck, it, tid, pre, wl, wr, r1s);
   __syncthreads();
-  condense_compute<WITH_RHS, MATS>(ck, it, tid, pre, buf, wl, wr, r1s, ncols, b_col_stride, vecs_col_stride);
+  condense_compute<WITH_RHS, MATS>(ck, it, tid, pre, buf, wl, wr, r1s, ncols, b_col_stride, vecs_col_stride, obuf);
 }
 
 // The same condensation, software-pipelined: a wavefront walks `per_block` consecutive stages and
@@ -504,6 +515,7 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
                            double *__restrict__ vecs_all, const long batch, const int per_block) {
   extern __shared__ double sm[];
   double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows, *r1s = wr + ck.lds_rows;
+  double *obuf = r1s + ((ck.n + ck.m + 1) & ~1);
   const int tid = threadIdx.x;
   const long total = batch * (ck.T + 1);
   const long first = (long)blockIdx.x * per_block;
@@ -553,7 +565,7 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
       condense_prefetch<WITH_RHS, true>(ck, cur, tid, pre);
       image_load(cur, img);
     }
-    condense_compute<WITH_RHS, true>(ck, nowit, tid, now, buf, wl, wr, r1s, 1, 0, 0);
+    condense_compute<WITH_RHS, true>(ck, nowit, tid, now, buf, wl, wr, r1s, 1, 0, 0, obuf);
     __syncthreads(); // every reader of the LDS image is done before it is overwritten
   }
 }

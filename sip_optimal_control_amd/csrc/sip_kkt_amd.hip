@@ -478,7 +478,8 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
     ck.lds_item = even(n * n + cgn * n + ck.edge_len);
     ck.lds_tail = even(cgn * n + cge * (n + mm)); // recover: every Jacobian of a stage
     ck.lds_rows = even(cgn + cge);                // condense: weights | weighted rhs rows
-    p->lds_chain_condense = sizeof(double) * ((size_t)ck.lds_item + 2 * (size_t)ck.lds_rows + n + mm);
+    // model image | weights | weighted rhs rows | r1 of the stage | the stage block of mats on its way out
+    p->lds_chain_condense = sizeof(double) * ((size_t)ck.lds_item + 2 * (size_t)ck.lds_rows + even(n + mm) + ck.mats_stage);
     p->lds_chain_recover = sizeof(double) * ((size_t)ck.lds_tail + n + mm);
     p->lds_chain_apply = sizeof(double) * ((size_t)ck.lds_item + 3 * n + mm + (size_t)ck.lds_rows);
     // lane maps of the chain kernels: state rows on lanes 0..n-1, control rows on lanes 32..32+m-1

@@ -84,3 +84,27 @@ def test_unsupported_plans_say_so():
     from sip_optimal_control_amd import BatchedChainLQR
     assert not BatchedChainLQR(5, 3, 4, 2, device="cuda:0").has_split      # a direct kernel
     assert not BatchedChainLQR(32, 8, 4, 2, dtype=torch.float32, device="cuda:0").has_split
+
+
+def test_split_at_the_headline_size():
+    """BASELINE.json's C3 (batch 4096, T = 50, n = 12, m = 4): the split sweep against the packed one, bitwise,
+    and the property the packed kernel is checked with at this size -- u_i = K_i x_i + k_i (lqr.cpp:856-857)."""
+    n, m, T, batch = 12, 4, 50, 4096
+    solver, mats, vecs = _problem(n, m, T, batch, seed=5)
+    if not solver.has_split:
+        pytest.skip("no split kernel")
+    sol, gains, status = (t.clone() for t in solver.factor_solve(mats, vecs))
+    qmr, ab = solver.split_inputs(mats)
+    sol2, gains2, status2 = solver.factor_solve_split(qmr, ab, vecs)
+    torch.cuda.synchronize()
+    assert int(status2.abs().sum()) == 0
+    assert torch.equal(sol, sol2) and torch.equal(gains, gains2)
+    vs = 2 * n + m
+    body = sol2[:, :T * vs].reshape(batch, T, vs)
+    x, u = body[:, :, :n], body[:, :, 2 * n:]
+    g = gains2.reshape(batch, T, m * n + m)
+    K = g[:, :, :m * n].reshape(batch, T, n, m)  # column-major m x n: element (j, c) at c * m + j
+    k = g[:, :, m * n:]
+    u_ref = torch.einsum("btcj,btc->btj", K, x) + k
+    scale = u.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1.0)
+    assert float(((u - u_ref).abs() / scale).max()) <= 1e-9
