@@ -522,10 +522,15 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
   const long end = first + per_block < total ? first + per_block : total;
   if (first >= end)
     return;
-  auto item_at = [&](const long idx) {
-    const long p = idx / (ck.T + 1);
-    return condense_item<WITH_RHS>(ck, p, (int)(idx - p * (ck.T + 1)), model_all, r1_all, inv_all, mats_all, b_all,
-                                   vecs_all);
+  // (problem, stage) of the walk: one 64-bit division for the first item, then counted on
+  long walk_p = first / (ck.T + 1);
+  int walk_i = (int)(first - walk_p * (ck.T + 1));
+  auto item_here = [&]() {
+    return condense_item<WITH_RHS>(ck, walk_p, walk_i, model_all, r1_all, inv_all, mats_all, b_all, vecs_all);
+  };
+  auto step_walk = [&]() {
+    if (++walk_i > ck.T)
+      walk_i = 0, ++walk_p;
   };
   // split: the pieces of ddyn_dx | ddyn_du are not fetched (nothing here reads them; the Riccati
   // sweep takes them from the arena itself) -- their lanes re-read the piece in front of them
@@ -542,7 +547,7 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
       v[u] = s2[q];
     }
   };
-  CondenseItem cur = item_at(first);
+  CondenseItem cur = item_here();
   CondensePre pre;
   d2_t img[PIPE_U];
   condense_prefetch<WITH_RHS, true>(ck, cur, tid, pre);
@@ -552,16 +557,16 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
       d2_t *d2 = (d2_t *)buf;
       const int len2 = (cur.node_len + cur.edge_len) >> 1;
 #pragma unroll
-      for (int u = 0; u < PIPE_U; ++u)
-        if (tid + u * TPB < len2)
-          d2[tid + u * TPB] = img[u];
+      for (int u = 0; u < PIPE_U; ++u) // (lanes past the end hold a copy of the last piece: the same store)
+        d2[min(tid + u * TPB, len2 - 1)] = img[u];
     }
     condense_commit<WITH_RHS, true>(ck, cur, tid, pre, wl, wr, r1s);
     __syncthreads();
     const CondensePre now = pre;
     const CondenseItem nowit = cur;
     if (idx + 1 < end) { // the next stage's loads fly during this stage's compute
-      cur = item_at(idx + 1);
+      step_walk();
+      cur = item_here();
       condense_prefetch<WITH_RHS, true>(ck, cur, tid, pre);
       image_load(cur, img);
     }
