@@ -86,6 +86,8 @@ using sipamd::KernelEntry;
 const KernelEntry kKernels[] = {
 #if defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_C4) // tools/ab_build.sh: one kernel alone, for A/B timing
     MF32(8),
+#elif defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_DIRECT)
+    QW16_DIRECT(15, 4), QW16_DIRECT(16, 4), QW16_DIRECT(11, 3),
 #elif defined(SIP_QW16_QUICK)
     QW16_STAGED(12, 4),
 #else
