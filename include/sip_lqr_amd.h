@@ -166,7 +166,7 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
  *           d_ab + (p * ab_problem_stride + i * ab_stage_stride) scalars.
  * 16-byte aligned bases and strides.  Available (sip_lqr_has_split() == 1) for fp64 plans whose fused
  * kernel is an LDS-staged one of the reference's Newton-KKT benchmark grid (n in {4, 6, 8, 12},
- * m in {2, 4}); SIP_LQR_ERR_UNSUPPORTED otherwise.  Everything else as sip_lqr_factor_solve. */
+ * m in {1, 2, 3, 4}); SIP_LQR_ERR_UNSUPPORTED otherwise.  Everything else as sip_lqr_factor_solve. */
 int sip_lqr_has_split(const sip_lqr_plan *plan);
 int64_t sip_lqr_split_mats_len(const sip_lqr_plan *plan);
 int sip_lqr_factor_solve_split(const sip_lqr_plan *plan, const void *d_mats, const void *d_ab,

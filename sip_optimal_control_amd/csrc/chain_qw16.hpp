@@ -300,6 +300,35 @@ struct StageDma {
   }
 };
 
+// The same lane-linear staging in 4-byte pieces (`global_load_lds_dword`, 256 bytes per instruction), for
+// regions whose length is an odd number of scalars (the gains K | k when M is odd): no byte past the
+// region is read -- a 16-byte piece would reach 8 bytes past the last problem's last stage.
+template <int DWORDS>
+struct StageDmaDwords {
+  static constexpr int INSTR = (4 * DWORDS + 63) / 64;
+  static constexpr int BYTES = (INSTR * 256 + 1023) / 1024 * 1024;
+  static constexpr int ROW_BYTES = DWORDS * 4;
+  unsigned off[INSTR > 0 ? INSTR : 1];
+  __device__ __forceinline__ void init(const int lane, const unsigned problem_stride_bytes, const unsigned max_rel) {
+    sfor<0, INSTR>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      const unsigned q = (unsigned)(j * 64 + lane) < 4u * DWORDS ? (unsigned)(j * 64 + lane) : 4u * DWORDS - 1u;
+      unsigned rr = q / DWORDS;
+      const unsigned within = q - rr * DWORDS;
+      rr = rr < max_rel ? rr : max_rel;
+      off[j] = rr * problem_stride_bytes + within * 4u;
+    });
+  }
+  template <int AUX = 0>
+  __device__ __forceinline__ void issue(const char *base, lds_char *dst, const int lane) const {
+    sfor<0, INSTR>([&](auto jj) { // whole-wave instructions only (see StageDma::issue)
+      constexpr int j = decltype(jj)::value;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off[j]),
+                                       (__attribute__((address_space(3))) void *)(dst + j * 256), 4, 0, AUX);
+    });
+  }
+};
+
 // The same staging with every instruction inside ONE problem's region: the image of problem rr
 // starts at rr * IP KiB (IP = instructions per problem, the region padded to whole instructions)
 // and instruction (rr, jj) moves its pieces [64 jj, 64 jj + 64).  All lanes then use the same byte
@@ -360,9 +389,12 @@ struct StagedCfg {
   // backward: whole stage block of mats + of vecs.  The per-problem form of the mats stream pads
   // every problem to whole instructions; it is taken unless that padding costs a wavefront per CU
   // (160 KiB of LDS: four wavefronts need <= 40 KiB each).
-  using BV = StageDma<(L::VNODE + L::VEDGE) / 2>;
-  using BMflat = StageDma<STG / 2>;
-  using BMrows = StageDmaRows<STG / 2>;
+  // (an odd number of scalars -- M odd -- takes one more 16-byte piece, whose second half is the first
+  // scalar of the block behind it: the next stage's, or the terminal node's; sources are then only
+  // 8-byte aligned, which the LDS-DMA of gfx950 copies exactly, tools/ubench/lds_dma_align.hip)
+  using BV = StageDma<(L::VNODE + L::VEDGE + 1) / 2>;
+  using BMflat = StageDma<(STG + 1) / 2>;
+  using BMrows = StageDmaRows<(STG + 1) / 2>;
   struct NoStream { // the A | B image of the unsplit kernel: none
     static constexpr int INSTR = 0, BYTES = 0, ROW_BYTES = 0;
   };
@@ -381,7 +413,7 @@ struct StagedCfg {
   static constexpr int B_BYTES = BM::BYTES + BA::BYTES + BV::BYTES;
   // forward: A|B, gains, S|g|h of the child, delta of the child
   using FA = StageDma<(N * N + N * M) / 2>;
-  using FG = StageDma<L::GAIN / 2>;
+  using FG = std::conditional_t<L::GAIN % 2 == 0, StageDma<L::GAIN / 2>, StageDmaDwords<2 * L::GAIN>>;
   using FW = StageDma<WSN / 2>;
   using FC = StageDma<N / 2>;
   static constexpr int F_BYTES = FA::BYTES + FG::BYTES + FW::BYTES + FC::BYTES;
@@ -400,7 +432,7 @@ struct StagedCfg {
   // vector lane, then one block of N zeros
   static constexpr int SCR_BYTES = ((4 * 2 * N + N) * 8 + 1023) / 1024 * 1024;
   static constexpr int LDS_BYTES = LDS_MAIN + SCR_BYTES;
-  static constexpr bool OK = (N % 2 == 0) && (M % 2 == 0);
+  static constexpr bool OK = N % 2 == 0; // columns of n scalars stay 16-byte aligned in the images
 };
 
 // Fused factor + solve.  STAGED: stage blocks travel HBM -> LDS by LDS-DMA one
@@ -440,7 +472,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, seg_last = 0;
   (void)seg, (void)seg_last;
   SIP_STAMP(ts_begin);
-  static_assert(!STAGED || C::OK, "staged kernel needs even N and M");
+  static_assert(!STAGED || C::OK, "staged kernel needs even N");
   constexpr int STG = C::STG;               // mats stage stride
   // M^T and R inside a mats stage block (A | B sit between the node part and them unless SPLIT)
   constexpr int OFF_M = L::NODE + (SPLIT ? 0 : N * N + N * M), OFF_R = OFF_M + N * M;
@@ -841,7 +873,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       }
       lds_cdouble *nm = (lds_cdouble *)(buf + rr * C::BM::ROW_BYTES);
       lds_cdouble *ea = SPLIT ? (lds_cdouble *)(buf + C::BM::BYTES + rr * C::BA::ROW_BYTES) : nm + L::NODE;
-      lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + C::BA::BYTES + rr * (VSTG * 8));
+      lds_cdouble *nv = (lds_cdouble *)(buf + C::BM::BYTES + C::BA::BYTES + rr * C::BV::ROW_BYTES);
       SIP_SEG(1);
       NodeTail nt;
       backward_edge(i, nm, ea, nv, nt);
@@ -1074,7 +1106,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       lds_char *b1 = buf + C::FA::BYTES, *b2 = b1 + C::FG::BYTES,
                *b3 = b2 + C::FW::BYTES;
       read_stage((lds_cdouble *)(buf + rr * ((N * N + N * M) * 8)),
-                 (lds_cdouble *)(b1 + rr * (L::GAIN * 8)),
+                 (lds_cdouble *)(b1 + rr * C::FG::ROW_BYTES),
                  (lds_cdouble *)(b2 + rr * (WSN * 8)),
                  (lds_cdouble *)(b3 + rr * (N * 8)));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -1,8 +1,8 @@
 // qw16_split.hip -- the split form of the fused chain sweep (chain_qw16.hpp, SPLIT): the stage blocks of
 // `mats` carry [Q | delta | M | R] and the dynamics Jacobians A | B stream from where the model callback
 // left them.  Used by the Newton-KKT step (sip_kkt_factor_solve), whose condensation then neither reads
-// nor copies A | B (helpers.cpp:365-366 copies them into the LQR inputs).  Compiled in two slices
-// (-DSIP_QW16_SPLIT_SLICE=0 / 1) beside the other translation units.
+// nor copies A | B (helpers.cpp:365-366 copies them into the LQR inputs).  Compiled in four slices
+// (-DSIP_QW16_SPLIT_SLICE=0..3) beside the other translation units.
 #include "qw16_launch.hpp"
 
 #ifndef SIP_QW16_SPLIT_SLICE
@@ -16,10 +16,12 @@ struct SplitEntry {
   launch_split_t launch;
 };
 const SplitEntry *qw16_split_slice_1(int *count);
+const SplitEntry *qw16_split_slice_2(int *count);
+const SplitEntry *qw16_split_slice_3(int *count);
 
 #define QW16_SPLIT(N, M) {N, M, &launch_qw16_split<N, M>}
-// the staged shapes of the reference's Newton-KKT benchmark grid (newton_kkt_benchmark.cpp:264-273) and
-// the f1 shape of bench.py
+// the staged shapes of the reference's Newton-KKT benchmark grid (newton_kkt_benchmark.cpp:264-273:
+// n in {4, 6, 8}, m in {1, 2, 3, 4}) and n = 12 (the f1 shape of bench.py and its fewer-control relatives)
 #if SIP_QW16_SPLIT_SLICE == 0
 
 namespace {
@@ -31,11 +33,14 @@ launch_split_t find_split_launch(int n, int m) {
     if (e.n == n && e.m == m)
       return e.launch;
 #if !defined(SIP_QW16_QUICK) && !defined(SIP_QW16_NO_EXTRA) // tools/ab_build.sh, tools/diag_build.sh link slice 0 alone
-  int count = 0;
-  const SplitEntry *more = qw16_split_slice_1(&count);
-  for (int k = 0; k < count; ++k)
-    if (more[k].n == n && more[k].m == m)
-      return more[k].launch;
+  typedef const SplitEntry *(*slice_fn)(int *);
+  for (const slice_fn fn : {qw16_split_slice_1, qw16_split_slice_2, qw16_split_slice_3}) {
+    int count = 0;
+    const SplitEntry *more = fn(&count);
+    for (int k = 0; k < count; ++k)
+      if (more[k].n == n && more[k].m == m)
+        return more[k].launch;
+  }
 #endif
   return nullptr;
 }
@@ -45,10 +50,18 @@ long split_mats_stage(int n, int m) { return (long)n * n + n + (long)n * m + (lo
 #else
 
 namespace {
+#if SIP_QW16_SPLIT_SLICE == 1
 const SplitEntry kSplit[] = {QW16_SPLIT(6, 4), QW16_SPLIT(8, 2), QW16_SPLIT(8, 4), QW16_SPLIT(12, 2)};
-}
+#elif SIP_QW16_SPLIT_SLICE == 2
+const SplitEntry kSplit[] = {QW16_SPLIT(12, 3), QW16_SPLIT(4, 1), QW16_SPLIT(4, 3), QW16_SPLIT(6, 1)};
+#else
+const SplitEntry kSplit[] = {QW16_SPLIT(12, 1), QW16_SPLIT(6, 3), QW16_SPLIT(8, 1), QW16_SPLIT(8, 3)};
+#endif
+} // namespace
 
-const SplitEntry *qw16_split_slice_1(int *count) {
+#define SIP_SPLIT_SLICE_FN_(S) qw16_split_slice_##S
+#define SIP_SPLIT_SLICE_FN(S) SIP_SPLIT_SLICE_FN_(S)
+const SplitEntry *SIP_SPLIT_SLICE_FN(SIP_QW16_SPLIT_SLICE)(int *count) {
   *count = (int)(sizeof(kSplit) / sizeof(kSplit[0]));
   return kSplit;
 }

@@ -90,25 +90,24 @@ def test_kernel_selection_and_embedding(lib, monkeypatch):
         for m in (1, 2, 3, 4):
             kernel, _ = name(n, m)
             assert f"qw16<{n},{m}," in kernel and "embedding" not in kernel
-            assert ("staged" in kernel) == (m % 2 == 0)
-    # every fp64 shape n <= 16, m <= 8 has an exact kernel (qw16_extra.hip); staged when both are even
+            assert "staged" in kernel  # odd m too: pieces from 8-byte-aligned sources, gains by dwords
+    # every fp64 shape n <= 16, m <= 8 has an exact kernel (qw16_extra.hip); staged when n is even and <= 14
     for n in range(1, 17):
         for m in range(1, 9):
             kernel, _ = name(n, m)
             assert f"qw16<{n},{m}," in kernel and "embedding" not in kernel, (n, m, kernel)
-            if n % 2 == 0 and m % 2 == 0 and n <= 14:
-                assert "staged" in kernel, (n, m, kernel)
+            assert ("staged" in kernel) == (n % 2 == 0 and n <= 14), (n, m, kernel)
     assert "tree_generic" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
     # without the extra slices (diagnostic builds; SIP_LQR_EXTRA=0): embedding in the next larger kernel
     monkeypatch.setenv("SIP_LQR_EXTRA", "0")
-    assert name(10, 3)[0] == "chain_factor_solve_qw16<12,4,staged>/f64 embedding (10,3)"
-    assert name(5, 3)[0].startswith("chain_factor_solve_qw16<6,4,staged>")
+    assert name(10, 3)[0] == "chain_factor_solve_qw16<12,3,staged>/f64 embedding (10,3)"
+    assert name(5, 3)[0].startswith("chain_factor_solve_qw16<6,3,staged>")
     assert name(13, 5)[0].startswith("chain_factor_solve_qw16<14,8,staged>")
     assert name(15, 7)[0].startswith("chain_factor_solve_qw16<15,8,direct>")
     assert "qw16<16,4,direct>" in name(16, 4)[0]  # distributed-vector mode
     assert "tree_generic" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
     assert "tree_generic" in name(10, 3, dtype=1)[0]  # fp32: only the n = 32 kernel is dedicated
-    exact_ws, embedded_ws = name(12, 4)[1], name(10, 3)[1]
+    exact_ws, embedded_ws = name(12, 3)[1], name(10, 3)[1]
     assert embedded_ws > exact_ws  # padded copies of mats / vecs / sol / gains live in the workspace
     monkeypatch.setenv("SIP_LQR_PAD", "0")
     assert "tree_generic" in name(10, 3)[0]
