@@ -398,6 +398,7 @@ struct StagedCfg {
   struct NoStream { // the A | B image of the unsplit kernel: none
     static constexpr int INSTR = 0, BYTES = 0, ROW_BYTES = 0;
   };
+  static_assert(!SPLIT || AB % 2 == 0, "the split kernels are instantiated for even N (A | B in whole 16-byte pieces)");
   using BA = std::conditional_t<SPLIT, StageDmaRows<AB / 2>, NoStream>;
   static constexpr int SCR_BYTES_ = ((4 * 2 * N + N) * 8 + 1023) / 1024 * 1024;
   static constexpr int waves_per_cu(int bm_bytes) {
@@ -412,10 +413,11 @@ struct StagedCfg {
 #endif
   static constexpr int B_BYTES = BM::BYTES + BA::BYTES + BV::BYTES;
   // forward: A|B, gains, S|g|h of the child, delta of the child
-  using FA = StageDma<(N * N + N * M) / 2>;
+  using FA = StageDma<(N * N + N * M + 1) / 2>; // (odd: N odd, M even -- its last half piece is M's first scalar)
   using FG = std::conditional_t<L::GAIN % 2 == 0, StageDma<L::GAIN / 2>, StageDmaDwords<2 * L::GAIN>>;
   using FW = StageDma<WSN / 2>;
-  using FC = StageDma<N / 2>;
+  // delta: the last N scalars of the terminal node end the problem's mats -- odd N streams them as dwords
+  using FC = std::conditional_t<N % 2 == 0, StageDma<N / 2>, StageDmaDwords<2 * N>>;
   static constexpr int F_BYTES = FA::BYTES + FG::BYTES + FW::BYTES + FC::BYTES;
   // LDS-DMA instructions per forward stage: the count the rollout's
   // `s_waitcnt vmcnt(F_GLDS)` relies on.
@@ -432,7 +434,8 @@ struct StagedCfg {
   // vector lane, then one block of N zeros
   static constexpr int SCR_BYTES = ((4 * 2 * N + N) * 8 + 1023) / 1024 * 1024;
   static constexpr int LDS_BYTES = LDS_MAIN + SCR_BYTES;
-  static constexpr bool OK = N % 2 == 0; // columns of n scalars stay 16-byte aligned in the images
+  static constexpr bool OK = N <= 15; // (N = 16: distributed-vector mode, direct loads only)
+  static constexpr bool WIDE = N % 2 == 0; // columns of n scalars are 16-byte aligned in the images: 16-byte LDS accesses
 };
 
 // Fused factor + solve.  STAGED: stage blocks travel HBM -> LDS by LDS-DMA one
@@ -472,7 +475,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, seg_last = 0;
   (void)seg, (void)seg_last;
   SIP_STAMP(ts_begin);
-  static_assert(!STAGED || C::OK, "staged kernel needs even N");
+  static_assert(!STAGED || C::OK, "no staged kernel for N = 16");
+  static_assert(!STAGED || C::LDS_BYTES <= 65536, "the LDS images of this shape exceed a workgroup's 64 KiB");
   constexpr int STG = C::STG;               // mats stage stride
   // M^T and R inside a mats stage block (A | B sit between the node part and them unless SPLIT)
   constexpr int OFF_M = L::NODE + (SPLIT ? 0 : N * N + N * M), OFF_R = OFF_M + N * M;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       constexpr int r = decltype(ii)::value;
       tv[r] = nt.cv[r] - nt.dv[r] * V[r];
     });
-    if constexpr (STAGED) {
+    if constexpr (STAGED && C::WIDE) {
       if (isV) { // 16-byte pairs (N even): ds_write_b128 at immediate offsets from one address
         typedef double d2 __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(3))) d2 lds_d2;
@@ -615,6 +619,14 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
           constexpr int k = decltype(kk)::value;
           t2[k] = d2{tv[2 * k], tv[2 * k + 1]};
           v2[k] = d2{V[2 * k], V[2 * k + 1]};
+        });
+      }
+    } else if constexpr (STAGED) {
+      if (isV) {
+        sfor<0, N>([&](auto ii) {
+          constexpr int r = decltype(ii)::value;
+          my_t[r] = tv[r];
+          my_v[r] = V[r];
         });
       }
     } else {
@@ -679,20 +691,27 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
         H[j] = isV ? msrc[j] : msrc[j * N];
       });
     }
-    if constexpr (STAGED) {
+    if constexpr (STAGED && C::WIDE) {
       // 16-byte aligned columns (N even): let the compiler use ds_read_b128
       typedef double d2 __attribute__((ext_vector_type(2)));
       typedef const __attribute__((address_space(3))) d2 lds_cd2;
       lds_cd2 *a_src = (lds_cd2 *)(isV ? (lds_cdouble *)my_t : ea + cm * N);
       lds_cd2 *f_src = (lds_cd2 *)(isV ? (lds_cdouble *)my_v : zeros);
       lds_cd2 *b_src = (lds_cd2 *)(ea + N * N + cu * N);
-      static_assert(N % 2 == 0, "staged kernel: even N");
       sfor<0, N / 2>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         const d2 a2 = a_src[k], f2 = f_src[k], b2 = b_src[k];
         Aaug[2 * k] = a2[0], Aaug[2 * k + 1] = a2[1]; // vector lane: t
         F[2 * k] = f2[0], F[2 * k + 1] = f2[1];       // vector lane accumulates g = v_c + W t
         Bcol[2 * k] = b2[0], Bcol[2 * k + 1] = b2[1];
+      });
+    } else if constexpr (STAGED) { // odd N: 8-byte LDS reads
+      lds_cdouble *a_src = isV ? (lds_cdouble *)my_t : ea + cm * N;
+      lds_cdouble *f_src = isV ? (lds_cdouble *)my_v : zeros;
+      lds_cdouble *b_src = ea + N * N + cu * N;
+      sfor<0, N>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        Aaug[k] = a_src[k], F[k] = f_src[k], Bcol[k] = b_src[k];
       });
     } else {
       sfor<0, N>([&](auto kk) {
@@ -1105,10 +1124,10 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       acc_fwait += ts_b - ts_a;
       lds_char *b1 = buf + C::FA::BYTES, *b2 = b1 + C::FG::BYTES,
                *b3 = b2 + C::FW::BYTES;
-      read_stage((lds_cdouble *)(buf + rr * ((N * N + N * M) * 8)),
+      read_stage((lds_cdouble *)(buf + rr * C::FA::ROW_BYTES),
                  (lds_cdouble *)(b1 + rr * C::FG::ROW_BYTES),
                  (lds_cdouble *)(b2 + rr * (WSN * 8)),
-                 (lds_cdouble *)(b3 + rr * (N * 8)));
+                 (lds_cdouble *)(b3 + rr * C::FC::ROW_BYTES));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (C::F_NBUF == 2 && i + 1 < T) // one stage ahead, behind this stage's arithmetic
         issue_forward(i + 1, lds + (fbuf ^ 1) * C::F_BYTES);

@@ -87,13 +87,14 @@ const KernelEntry kKernels[] = {
 #if defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_C4) // tools/ab_build.sh: one kernel alone, for A/B timing
     MF32(8),
 #elif defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_DIRECT)
-    QW16_STAGED(10, 3), QW16_DIRECT(10, 3), QW16_STAGED(6, 3), QW16_DIRECT(6, 3), QW16_STAGED(12, 3), QW16_DIRECT(12, 3),
+    QW16_STAGED(11, 3), QW16_DIRECT(11, 3), QW16_STAGED(13, 5), QW16_DIRECT(13, 5), QW16_STAGED(9, 2), QW16_DIRECT(9, 2),
+    QW16_STAGED(7, 3), QW16_DIRECT(7, 3), QW16_STAGED(15, 4), QW16_DIRECT(15, 4), QW16_STAGED(5, 3), QW16_DIRECT(5, 3),
 #elif defined(SIP_QW16_QUICK)
     QW16_STAGED(12, 4),
 #else
     MF32(8), QW16_STAGED_MR(12, 4), QW16_STAGED_MR(4, 2), QW16_DIRECT(12, 4),
-    QW16_DIRECT(4, 2),  QW16_DIRECT(1, 1), QW16_STAGED(2, 1),
-    QW16_DIRECT(3, 2),  QW16_STAGED_MR(8, 3),
+    QW16_DIRECT(4, 2),  QW16_STAGED(1, 1), QW16_STAGED(2, 1),
+    QW16_STAGED(3, 2),  QW16_STAGED_MR(8, 3),
     // the grid of the reference's benchmarks (lqr_benchmark.cpp:537-545,
     // newton_kkt_benchmark.cpp:264-273: n in {4, 6, 8}, m in {1, 2, 3, 4}; n = 16 has no
     // vector lane left and runs on the general engine) and n = 12 with fewer controls
@@ -102,7 +103,7 @@ const KernelEntry kKernels[] = {
     QW16_STAGED_MR(6, 1),  QW16_STAGED_MR(6, 3),  QW16_STAGED_MR(8, 1),  QW16_STAGED_MR(12, 1),
     QW16_STAGED_MR(12, 3),
     // hosts for the embedding of larger shapes (n <= 15: one lane of the row carries the affine column)
-    QW16_STAGED(8, 8),  QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(14, 8), QW16_DIRECT(15, 4),
+    QW16_STAGED(8, 8),  QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(14, 8), QW16_STAGED(15, 4),
     QW16_DIRECT(15, 8),
     // n = 16 (in the reference's benchmark grid): distributed-vector mode, see chain_qw16.hpp
     QW16_DIRECT_MR(16, 1), QW16_DIRECT_MR(16, 2), QW16_DIRECT_MR(16, 3), QW16_DIRECT_MR(16, 4), QW16_DIRECT(16, 8),

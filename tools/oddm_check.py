@@ -1,7 +1,8 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from sip_optimal_control_amd import BatchedChainLQR, ChainShape, synthetic
-for (n, m) in ((10, 3), (6, 3), (12, 3)):
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(10, 3), (6, 3), (12, 3)]
+for (n, m) in shapes:
     for T, batch in ((50, 37), (7, 5), (1, 3), (50, 4096)):
         res = {}
         for variant in ("staged", "direct"):
