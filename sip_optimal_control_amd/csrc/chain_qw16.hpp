@@ -434,7 +434,7 @@ struct StagedCfg {
   // vector lane, then one block of N zeros
   static constexpr int SCR_BYTES = ((4 * 2 * N + N) * 8 + 1023) / 1024 * 1024;
   static constexpr int LDS_BYTES = LDS_MAIN + SCR_BYTES;
-  static constexpr bool OK = N <= 15; // (N = 16: distributed-vector mode, direct loads only)
+  static constexpr bool OK = N <= 16;
   static constexpr bool WIDE = N % 2 == 0; // columns of n scalars are 16-byte aligned in the images: 16-byte LDS accesses
 };
 
@@ -462,7 +462,6 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   // matrix-vector product of the sweep is one dotv block (VDIST mode; direct loads only).
   constexpr bool VDIST = N == 16;
   static_assert(N >= 1 && N <= 16, "one problem per 16-lane row");
-  static_assert(!(VDIST && STAGED), "N = 16 is instantiated without LDS staging");
   static_assert(M >= 1 && M <= 16, "");
   using L = ChainLayout<N, M>;
   using C = StagedCfg<N, M, WPACK, SPLIT>;
@@ -475,7 +474,6 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, seg_last = 0;
   (void)seg, (void)seg_last;
   SIP_STAMP(ts_begin);
-  static_assert(!STAGED || C::OK, "no staged kernel for N = 16");
   static_assert(!STAGED || C::LDS_BYTES <= 65536, "the LDS images of this shape exceed a workgroup's 64 KiB");
   constexpr int STG = C::STG;               // mats stage stride
   // M^T and R inside a mats stage block (A | B sit between the node part and them unless SPLIT)

@@ -87,8 +87,7 @@ const KernelEntry kKernels[] = {
 #if defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_C4) // tools/ab_build.sh: one kernel alone, for A/B timing
     MF32(8),
 #elif defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_DIRECT)
-    QW16_STAGED(11, 3), QW16_DIRECT(11, 3), QW16_STAGED(13, 5), QW16_DIRECT(13, 5), QW16_STAGED(9, 2), QW16_DIRECT(9, 2),
-    QW16_STAGED(7, 3), QW16_DIRECT(7, 3), QW16_STAGED(15, 4), QW16_DIRECT(15, 4), QW16_STAGED(5, 3), QW16_DIRECT(5, 3),
+    QW16_STAGED(16, 4), QW16_DIRECT(16, 4), QW16_STAGED(16, 1), QW16_DIRECT(16, 1), QW16_STAGED(16, 3), QW16_DIRECT(16, 3),
 #elif defined(SIP_QW16_QUICK)
     QW16_STAGED(12, 4),
 #else
