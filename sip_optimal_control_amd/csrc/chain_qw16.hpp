@@ -423,13 +423,22 @@ struct StagedCfg {
   // `s_waitcnt vmcnt(F_GLDS)` relies on.
   static constexpr int F_GLDS = FA::INSTR + FG::INSTR + FW::INSTR + FC::INSTR;
   static constexpr int B_NBUF = 2; // backward: one stage ahead
-#ifndef SIP_LQR_FNBUF
-#define SIP_LQR_FNBUF 3
+  // forward: F_NBUF - 1 stages ahead.  Three buffers (two stages of lookahead) unless the third one
+  // costs a wavefront per CU (160 KiB of LDS): there the occupancy is worth more than the lookahead --
+  // (12,6) 0.47 -> 0.36 ms, (13,5) 0.51 -> 0.40, (12,8) 0.52 -> 0.42, (14,4) 0.54 -> 0.44 at batch 4096.
+  static constexpr int lds_main(int fbufs) {
+    return B_NBUF * B_BYTES > fbufs * F_BYTES ? B_NBUF * B_BYTES : fbufs * F_BYTES;
+  }
+  static constexpr int waves_with(int fbufs) {
+    const int w = 163840 / (lds_main(fbufs) + SCR_BYTES_);
+    return w > 4 ? 4 : w;
+  }
+#ifdef SIP_LQR_FNBUF
+  static constexpr int F_NBUF = SIP_LQR_FNBUF;
+#else
+  static constexpr int F_NBUF = (waves_with(2) > waves_with(3) || lds_main(3) + SCR_BYTES_ > 65536) ? 2 : 3; // (or it would not fit at all)
 #endif
-  static constexpr int F_NBUF = SIP_LQR_FNBUF; // forward: F_NBUF-1 stages ahead
-  static constexpr int LDS_MAIN = B_NBUF * B_BYTES > F_NBUF * F_BYTES
-                                      ? B_NBUF * B_BYTES
-                                      : F_NBUF * F_BYTES;
+  static constexpr int LDS_MAIN = lds_main(F_NBUF);
   // per-row scratch behind the stage buffers: t (N) | v_child (N) of the
   // vector lane, then one block of N zeros
   static constexpr int SCR_BYTES = ((4 * 2 * N + N) * 8 + 1023) / 1024 * 1024;

@@ -87,7 +87,7 @@ const KernelEntry kKernels[] = {
 #if defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_C4) // tools/ab_build.sh: one kernel alone, for A/B timing
     MF32(8),
 #elif defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_DIRECT)
-    QW16_STAGED(16, 4), QW16_DIRECT(16, 4), QW16_STAGED(16, 1), QW16_DIRECT(16, 1), QW16_STAGED(16, 3), QW16_DIRECT(16, 3),
+    QW16_STAGED(14, 8), QW16_STAGED(15, 4), QW16_STAGED(13, 5), QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(12, 6),
 #elif defined(SIP_QW16_QUICK)
     QW16_STAGED(12, 4),
 #else
@@ -103,7 +103,7 @@ const KernelEntry kKernels[] = {
     QW16_STAGED_MR(12, 3),
     // hosts for the embedding of larger shapes (n <= 15: one lane of the row carries the affine column)
     QW16_STAGED(8, 8),  QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(14, 8), QW16_STAGED(15, 4),
-    QW16_DIRECT(15, 8),
+    QW16_STAGED(15, 8),
     // n = 16 (in the reference's benchmark grid): distributed-vector mode, see chain_qw16.hpp
     QW16_DIRECT_MR(16, 1), QW16_DIRECT_MR(16, 2), QW16_DIRECT_MR(16, 3), QW16_DIRECT_MR(16, 4), QW16_DIRECT(16, 8),
 #endif

@@ -92,19 +92,19 @@ def test_kernel_selection_and_embedding(lib, monkeypatch):
             assert f"qw16<{n},{m}," in kernel and "embedding" not in kernel
             assert "staged" in kernel  # odd m too: pieces from 8-byte-aligned sources, gains by dwords
     # every fp64 shape n <= 16, m <= 8 has an exact kernel (qw16_extra.hip); LDS-staged wherever its images fit a
-    # workgroup's 64 KiB: all but (15, 7), (15, 8) and n = 16 (distributed-vector mode, direct loads)
+    # workgroup's 64 KiB: all n <= 15; n = 16 (distributed-vector mode) stays on direct loads
     for n in range(1, 17):
         for m in range(1, 9):
             kernel, _ = name(n, m)
             assert f"qw16<{n},{m}," in kernel and "embedding" not in kernel, (n, m, kernel)
-            assert ("staged" in kernel) == (n <= 15 and (n, m) not in ((15, 7), (15, 8))), (n, m, kernel)
+            assert ("staged" in kernel) == (n <= 15), (n, m, kernel)
     assert "tree_generic" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
     # without the extra slices (diagnostic builds; SIP_LQR_EXTRA=0): embedding in the next larger kernel
     monkeypatch.setenv("SIP_LQR_EXTRA", "0")
     assert name(10, 3)[0] == "chain_factor_solve_qw16<12,3,staged>/f64 embedding (10,3)"
     assert name(5, 3)[0].startswith("chain_factor_solve_qw16<6,3,staged>")
     assert name(13, 5)[0].startswith("chain_factor_solve_qw16<14,8,staged>")
-    assert name(15, 7)[0].startswith("chain_factor_solve_qw16<15,8,direct>")
+    assert name(15, 7)[0].startswith("chain_factor_solve_qw16<15,8,staged>")
     assert name(15, 3)[0].startswith("chain_factor_solve_qw16<15,4,staged>")
     assert "qw16<16,4,direct>" in name(16, 4)[0]  # distributed-vector mode
     assert "tree_generic" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
