@@ -506,8 +506,8 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
 // load time + compute time + store time (245 + 180 + 110 us at the f1 shape).  Requires the stage
 // image to be one pass of 16-byte pieces: (node_len + edge_len) / 2 <= PIPE_U * 64, even lengths,
 // 16-byte aligned arenas (checked on the host).
-// (Occupancy is not what holds it back: capped at 128 / 96 registers -- 4 / 5 wavefronts per SIMD instead of 3 --
-// the Newton-KKT step took 0.95 / 1.42 ms instead of 0.92.)
+// (Three wavefronts per SIMD -- what its 156 registers give -- is the best occupancy for it: capped to 2, 4 or 5 the
+// Newton-KKT step took 1.06 / 0.95 / 1.42 ms instead of 0.92.)
 constexpr int PIPE_U = 8;
 template <bool WITH_RHS>
 __global__ void __launch_bounds__(TPB)
