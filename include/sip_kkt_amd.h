@@ -150,7 +150,13 @@ int sip_kkt_solve(const sip_kkt_plan *plan, const double *d_model,
 
 /* factor() followed by solve() (the loop body of BM_NewtonKKTFactorSolve,
  * benchmarks/newton_kkt_benchmark.cpp:316-324), with the Riccati part as the
- * fused launch of sip_lqr_factor_solve() when the plan is a uniform chain. */
+ * fused launch of sip_lqr_factor_solve() when the plan is a uniform chain
+ * (sip_lqr_factor_solve_split where the plan's kernel has that form: the
+ * dynamics Jacobians are then read in place, not copied, helpers.cpp:365-366).
+ * It does NOT leave the factor state sip_kkt_solve() works from -- the fused
+ * sweep keeps none, and d_work holds the inputs in the fused sweep's own
+ * layout: for further right-hand sides on one factorization call
+ * sip_kkt_factor() and then sip_kkt_solve() as often as needed. */
 int sip_kkt_factor_solve(const sip_kkt_plan *plan, const double *d_model,
                          const double *d_w, const double *d_r1,
                          const double *d_r2, const double *d_r3,
