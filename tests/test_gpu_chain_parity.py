@@ -161,3 +161,25 @@ def test_empty_horizon_and_single_problem():
         ref_sol, _, ref_status = oracle.chain_batch(n, m, T, mats.cpu().numpy(), vecs.cpu().numpy())
         np.testing.assert_array_equal(status.cpu().numpy(), ref_status)
         assert _rel(sol.cpu().numpy(), ref_sol) <= TOL
+
+
+@pytest.mark.parametrize("n,m", [(6, 3), (11, 3), (12, 6), (13, 5), (15, 7)])
+def test_odd_and_large_shapes_at_full_batch(oracle_lib, n, m):
+    """The LDS-staged kernels of odd dimensions (16-byte pieces from 8-byte-aligned sources, 4-byte pieces for
+    the gains / the terminal delta) and of the shapes that keep two rollout buffers, at BASELINE's batch and
+    horizon: every problem against the oracle, and u_i = K_i x_i + k_i (lqr.cpp:856-857)."""
+    T, batch = 50, 4096
+    shape, mats, vecs, sol, gains, status = _run(n, m, T, batch, seed=77 + 3 * n + m)
+    from sip_optimal_control_amd import BatchedChainLQR
+    assert "staged" in BatchedChainLQR(n, m, T, batch, device="cuda:0").kernel_name
+    ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(n, m, T, mats, vecs)
+    np.testing.assert_array_equal(status, ref_status)
+    assert (ref_status == 0).all()
+    assert _rel(sol, ref_sol) <= TOL and _rel(gains, ref_gains) <= TOL
+    vs = 2 * n + m
+    body = sol[:, :T * vs].reshape(batch, T, vs)
+    x, u = body[:, :, :n], body[:, :, 2 * n:]
+    g = gains.reshape(batch, T, m * n + m)
+    K, k = g[:, :, :m * n].reshape(batch, T, n, m), g[:, :, m * n:]  # K column-major m x n: (j, c) at c * m + j
+    u_ref = np.einsum("btcj,btc->btj", K, x) + k
+    assert (np.abs(u - u_ref) / np.maximum(np.abs(u).max(axis=(1, 2), keepdims=True), 1.0)).max() <= 1e-9
