@@ -508,6 +508,19 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
 // 16-byte aligned arenas (checked on the host).
 // (Three wavefronts per SIMD -- what its 156 registers give -- is the best occupancy for it: capped to 2, 4 or 5 the
 // Newton-KKT step took 1.06 / 0.95 / 1.42 ms instead of 0.92.)
+#ifdef SIP_KKT_STAMPS // diagnostic build (tools/kkt_ab_build.sh ... -DSIP_KKT_STAMPS): cycles per segment, summed over wavefronts
+__device__ unsigned long long g_kkt_seg[16];
+#define KKT_SEG(k)                                                                                   \
+  do {                                                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                    \
+    seg[k] += now_ - seg_last;                                                                       \
+    seg_last = now_;                                                                                 \
+  } while (0)
+#else
+#define KKT_SEG(k)                                                                                   \
+  do {                                                                                               \
+  } while (0)
+#endif
 constexpr int PIPE_U = 8;
 template <bool WITH_RHS>
 __global__ void __launch_bounds__(TPB)
@@ -549,11 +562,15 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
       v[u] = s2[q];
     }
   };
+#ifdef SIP_KKT_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seg_last = __builtin_amdgcn_s_memtime();
+#endif
   CondenseItem cur = item_here();
   CondensePre pre;
   d2_t img[PIPE_U];
   condense_prefetch<WITH_RHS, true>(ck, cur, tid, pre);
   image_load(cur, img);
+  KKT_SEG(0);
   for (long idx = first; idx < end; ++idx) {
     { // registers -> LDS
       d2_t *d2 = (d2_t *)buf;
@@ -562,8 +579,10 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
       for (int u = 0; u < PIPE_U; ++u) // (lanes past the end hold a copy of the last piece: the same store)
         d2[min(tid + u * TPB, len2 - 1)] = img[u];
     }
+    KKT_SEG(1); // wait for the image + its stores to LDS
     condense_commit<WITH_RHS, true>(ck, cur, tid, pre, wl, wr, r1s);
     __syncthreads();
+    KKT_SEG(2);
     const CondensePre now = pre;
     const CondenseItem nowit = cur;
     if (idx + 1 < end) { // the next stage's loads fly during this stage's compute
@@ -572,9 +591,17 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
       condense_prefetch<WITH_RHS, true>(ck, cur, tid, pre);
       image_load(cur, img);
     }
+    KKT_SEG(3); // issue of the next stage's loads
     condense_compute<WITH_RHS, true>(ck, nowit, tid, now, buf, wl, wr, r1s, 1, 0, 0, obuf);
+    KKT_SEG(4);
     __syncthreads(); // every reader of the LDS image is done before it is overwritten
+    KKT_SEG(5);
   }
+#ifdef SIP_KKT_STAMPS
+  if (tid == 0)
+    for (int k = 0; k < 8; ++k)
+      atomicAdd(&g_kkt_seg[k], seg[k]);
+#endif
 }
 
 // x, u, y scatter + multipliers of node i and edge i (helpers.cpp:817-892).  COLS: the instantiation

@@ -947,4 +947,14 @@ int sip_kkt_add_Kx_to_y_theta(const sip_kkt_plan *p, const double *d_model, cons
                       (hipStream_t)stream, "sip_kkt_add_Kx_to_y_theta");
 }
 
+#ifdef SIP_KKT_STAMPS
+// diagnostic build: read (and clear) the per-segment cycle sums of condense_chain_pipe_kernel
+void sip_kkt_debug_segments(unsigned long long *out16) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sipamd::kkt::g_kkt_seg), 16 * sizeof(unsigned long long));
+  unsigned long long zero[16] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(sipamd::kkt::g_kkt_seg), zero, sizeof(zero));
+}
+#endif
+
 } // extern "C"
