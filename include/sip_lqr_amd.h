@@ -164,7 +164,9 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
  *           chain layout, edge blocks [M | R] (no A, B);
  *   d_ab  : stage i of problem p: A (n x n, column-major) then B (n x m, column-major) at
  *           d_ab + (p * ab_problem_stride + i * ab_stage_stride) scalars.
- * 16-byte aligned bases and strides.  Available (sip_lqr_has_split() == 1) for fp64 plans whose fused
+ * 16-byte aligned bases and strides; 3 * ab_problem_stride * 8 + (n*n + n*m) * 8 < 2^32 bytes (the four
+ * problems of a wavefront are addressed by 32-bit offsets; SIP_LQR_ERR_INVALID_ARGUMENT beyond: that is
+ * a problem stride of up to ~178 M scalars).  Available (sip_lqr_has_split() == 1) for fp64 plans whose fused
  * kernel is an LDS-staged one of the reference's Newton-KKT benchmark grid (n in {4, 6, 8, 12},
  * m in {1, 2, 3, 4}); SIP_LQR_ERR_UNSUPPORTED otherwise.  Everything else as sip_lqr_factor_solve. */
 int sip_lqr_has_split(const sip_lqr_plan *plan);

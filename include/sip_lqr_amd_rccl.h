@@ -58,6 +58,7 @@ int sip_lqr_all_gather_gains(const sip_lqr_plan *plan, void *nccl_comm, const vo
 int sip_lqr_gains_chunk_range(const sip_lqr_plan *plan, int chunk, int num_chunks, int64_t *first_problem,
                               int64_t *num_problems);
 size_t sip_lqr_gains_chunk_offset(const sip_lqr_plan *plan, int nranks, int rank, int chunk, int num_chunks);
+/* `nranks` must be the size of `nccl_comm` (checked: the chunk's place in the gathered buffer follows from it). */
 int sip_lqr_all_gather_gains_chunk(const sip_lqr_plan *plan, void *nccl_comm, int nranks, const void *d_gains,
                                    void *d_all_gains, int chunk, int num_chunks, void *stream);
 int sip_lqr_group_all_gather_gains_chunk(sip_lqr_group *group, const sip_lqr_plan *const *plans,
@@ -68,12 +69,26 @@ int sip_lqr_group_all_gather_gains_chunk(sip_lqr_group *group, const sip_lqr_pla
  * (rank, peer) pair on a stream of its own, so that the seven links of a GPU carry its shard to the
  * seven peers at the same time (a ring would push the shard through one link seven times).  Rank-major
  * layout, as sip_lqr_group_all_gather_gains.  Each copy waits for the work enqueued on streams[i] when
- * the call is made, and streams[i] waits for the copies INTO rank i, so the usual stream semantics hold.
+ * the call is made; streams[i] then waits for the copies INTO rank i and for the copies OUT of rank i,
+ * so both buffers follow ncclAllGather's stream semantics: behind the call on streams[i], d_all_gains[i]
+ * is complete and d_gains[i] may be rewritten.
  * Needs peer access between all devices of the group (enabled by sip_lqr_group_create where the
  * hardware offers it; SIP_LQR_ERR_UNSUPPORTED otherwise). */
 int sip_lqr_group_all_gather_gains_p2p(sip_lqr_group *group, const sip_lqr_plan *const *plans,
                                        const void *const *d_gains, void *const *d_all_gains,
                                        void *const *streams);
+
+/* Chunk form with a completion stream of the caller's choice: chunk `chunk` of `num_chunks` of every
+ * rank, chunk-major layout (sip_lqr_gains_chunk_offset).  streams[i] is the stream whose work produces
+ * rank i's chunk (the copies wait for what it holds at call time); done_streams[i] (NULL array: the
+ * same as streams) is the stream that is made to wait for the copies into AND out of rank i, and whose
+ * work at call time the copies into rank i wait for (consumers of the previous contents of the gathered
+ * buffer live there).  With a done stream of its own the compute stream is not held up by the exchange:
+ * the next sweep overlaps it, provided the caller double-buffers d_gains (or makes the compute stream
+ * wait for the done stream before it rewrites them).  Chunks of one pair travel in call order. */
+int sip_lqr_group_all_gather_gains_p2p_chunk(sip_lqr_group *group, const sip_lqr_plan *const *plans,
+                                             const void *const *d_gains, void *const *d_all_gains, int chunk,
+                                             int num_chunks, void *const *streams, void *const *done_streams);
 
 #ifdef __cplusplus
 }

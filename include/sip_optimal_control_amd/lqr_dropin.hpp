@@ -366,7 +366,10 @@ public:
     return on;
   }
   void set_fused_chains(bool on) { fused_chains_ = on; }
-  bool uses_fused_chain_kernel() { return fast_chain() != nullptr; }
+  bool uses_fused_chain_kernel() {
+    OnDevice on_device(device_ordinal_);
+    return fast_chain() != nullptr;
+  }
 
   // Replaces compile_topology_data (lqr.cpp:563-631); fills the traversal
   // arrays of the caller's workspace (read by helpers.cpp:217-218, 521-665 and
@@ -387,6 +390,7 @@ public:
   FactorStatus factor_with_status() {
     if (traversal_status_ != FactorStatus::SUCCESS)
       return traversal_status_;
+    OnDevice on_device(device_ordinal_); // copies and null-stream kernels on the plan's device; caller's restored
     if (FastChain *f = fast_chain())
       return fast_factor(*f);
     Device &d = device();
@@ -403,6 +407,7 @@ public:
 
   // Replaces lqr.cpp:735-871; requires a preceding successful factor.
   void solve(Output &output) {
+    OnDevice on_device(device_ordinal_);
     if (FastChain *f = fast_chain())
       return fast_solve(*f, output);
     Device &d = device();
@@ -433,6 +438,27 @@ public:
   }
 
 private:
+  // Make the object's device current for the duration of a call and restore the caller's on return: the
+  // synchronous copies and the plan's null-stream kernels then share one device's null stream, whatever
+  // device the host program had current (a multi-GPU host switches between calls).
+  struct OnDevice {
+    int previous = -1;
+    explicit OnDevice(int ordinal) {
+      if (hipGetDevice(&previous) != hipSuccess)
+        previous = -1;
+      if (previous != ordinal)
+        check_hip(hipSetDevice(ordinal), "hipSetDevice");
+      else
+        previous = -1;
+    }
+    ~OnDevice() {
+      if (previous >= 0)
+        (void)hipSetDevice(previous);
+    }
+    OnDevice(const OnDevice &) = delete;
+    OnDevice &operator=(const OnDevice &) = delete;
+  };
+
   // Device-side state of one LQR object (plan + arenas for a batch of one).
   struct Device {
     sip_lqr_tree_plan *plan = nullptr;
@@ -506,7 +532,6 @@ private:
         return nullptr;
     FastChain &f = *fast_;
     f.n = n, f.m = m, f.T = E;
-    check_hip(hipSetDevice(device_ordinal_), "hipSetDevice");
     check(sip_lqr_plan_create(SIP_LQR_F64, 1, E, n, m, device_ordinal_, &f.plan), "sip_lqr_plan_create");
     f.h_mats.assign(sip_lqr_mats_len(f.plan), 0.0), f.h_vecs.assign(sip_lqr_vecs_len(f.plan), 0.0);
     f.h_sol.assign(sip_lqr_vecs_len(f.plan), 0.0), f.h_gains.assign(sip_lqr_gains_len(f.plan), 0.0);
@@ -563,7 +588,6 @@ private:
     auto d = std::make_unique<Device>();
     const Topology &t = input_.topology;
     const Dimensions &dims = input_.dimensions;
-    check_hip(hipSetDevice(device_ordinal_), "hipSetDevice"); // the arenas below live on the plan's device
     check(sip_lqr_tree_plan_create(1, t.num_edges, t.root, t.edge_parents, t.edge_children, dims.state_dims,
                                    dims.control_dims, device_ordinal_, &d->plan),
           "sip_lqr_tree_plan_create");

@@ -11,7 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liblqr_oracle.so")
+_SO_NATIVE = os.path.join(_HERE, "liblqr_oracle_native.so")
 _lib = None
+_lib_native = None
 
 STATUS_NAMES = {0: "SUCCESS", 1: "INVALID_DELTA", 2: "F_FACTORIZATION_FAILURE",
                 3: "G_FACTORIZATION_FAILURE", 4: "INVALID_TOPOLOGY"}
@@ -45,12 +47,50 @@ def build(force=False):
     return _SO
 
 
-def lib():
-    global _lib
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def build_native(force=False):
+    """Second build of the same two C files for the TIMED cpu_baseline of bench.py only:
+    -O3 -march=native with FMA contraction on, built on the host that times it
+    (the sidecar records the CPU model: a library that travelled from another machine is rebuilt).
+    The parity oracle stays the -ffp-contract=off build above."""
+    sources = [os.path.join(_HERE, f) for f in ("lqr_oracle.c", "lqr_oracle.h", "kkt_oracle.c", "kkt_oracle.h")]
+    side = _SO_NATIVE + ".host"
+    tag = _cpu_model()
+    fresh = os.path.exists(_SO_NATIVE) and os.path.exists(side) and open(side).read().strip() == tag and \
+        os.path.getmtime(_SO_NATIVE) >= max(os.path.getmtime(f) for f in sources)
+    if force or not fresh:
+        if os.path.exists(_SO_NATIVE):
+            os.remove(_SO_NATIVE)
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+        with open(side, "w") as f:
+            f.write(tag + "\n")
+    return _SO_NATIVE
+
+
+def lib(native=False):
+    global _lib, _lib_native
+    if native:
+        if _lib_native is None:
+            _lib_native = _bind(ctypes.CDLL(build_native()))
+        return _lib_native
     if _lib is None:
         if not os.path.exists(_SO):
             build()
-        L = ctypes.CDLL(_SO)
+        _lib = _bind(ctypes.CDLL(_SO))
+    return _lib
+
+
+def _bind(L):
+    if True:
         L.lqr_oracle_workspace_reserve.argtypes = [ctypes.POINTER(_Workspace), ctypes.POINTER(_Problem)]
         L.lqr_oracle_workspace_free.argtypes = [ctypes.POINTER(_Workspace)]
         L.lqr_oracle_workspace_free.restype = None
@@ -64,8 +104,7 @@ def lib():
             fn = getattr(L, f"lqr_oracle_chain_{name}_len")
             fn.argtypes = [ctypes.c_int] * 3
             fn.restype = ctypes.c_long
-        _lib = L
-    return _lib
+    return L
 
 
 def _ptr_table(arrays):
@@ -160,9 +199,10 @@ class TreeLQR:
             pass
 
 
-def chain_batch(n, m, T, mats, vecs, threads=1, want_gains=True):
-    """Run the oracle over a packed uniform-chain batch (numpy float64 [batch, len])."""
-    L = lib()
+def chain_batch(n, m, T, mats, vecs, threads=1, want_gains=True, native=False):
+    """Run the oracle over a packed uniform-chain batch (numpy float64 [batch, len]).
+    native: the -march=native / FMA build (timing only, never parity)."""
+    L = lib(native)
     mats = np.ascontiguousarray(mats, dtype=np.float64)
     vecs = np.ascontiguousarray(vecs, dtype=np.float64)
     batch = mats.shape[0]

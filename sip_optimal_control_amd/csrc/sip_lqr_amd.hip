@@ -647,6 +647,11 @@ int sip_lqr_factor_solve_split(const sip_lqr_plan *plan, const void *d_mats, con
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   if (!sip_lqr_has_split(plan))
     return SIP_LQR_ERR_UNSUPPORTED;
+  // The staging code addresses the four problems of a wavefront by 32-bit byte offsets from the first
+  // one's A | B: three problem strides plus one stage image must stay below 2^32 bytes.
+  const uint64_t ab_block_bytes = ((uint64_t)plan->n * plan->n + (uint64_t)plan->n * plan->m) * 8u;
+  if ((uint64_t)ab_problem_stride > (((uint64_t)1 << 32) - 1 - ab_block_bytes) / (3u * 8u))
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
   if (require_device(plan) != hipSuccess)
     return report(hipErrorNoDevice, "sip_lqr_factor_solve_split");
   sipamd::DeviceGuard on_device(plan->device);

@@ -14,7 +14,8 @@ struct sip_lqr_group {
   // direct peer copies: one stream per (source rank, destination rank) pair, on the source device
   bool peer_ok = false;
   std::vector<hipStream_t> pair_streams;
-  std::vector<hipEvent_t> ready, landed; // per rank: work of streams[i] at call time; per pair: copy done
+  // per rank: work of streams[i] / of done_streams[i] at call time; per pair: copy done
+  std::vector<hipEvent_t> ready, ready_done, landed;
 };
 
 namespace {
@@ -69,9 +70,11 @@ int sip_lqr_group_create(int ndev, const int *devices, sip_lqr_group **out) {
     g->pair_streams.assign((size_t)ndev * ndev, nullptr);
     g->landed.assign((size_t)ndev * ndev, nullptr);
     g->ready.assign((size_t)ndev, nullptr);
+    g->ready_done.assign((size_t)ndev, nullptr);
     for (int i = 0; i < ndev && g->peer_ok; ++i) {
       g->peer_ok = hipSetDevice(g->devices[i]) == hipSuccess &&
-                   hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming) == hipSuccess;
+                   hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&g->ready_done[i], hipEventDisableTiming) == hipSuccess;
       for (int j = 0; j < ndev && g->peer_ok; ++j)
         g->peer_ok = hipStreamCreateWithFlags(&g->pair_streams[(size_t)i * ndev + j], hipStreamNonBlocking) == hipSuccess &&
                      hipEventCreateWithFlags(&g->landed[(size_t)i * ndev + j], hipEventDisableTiming) == hipSuccess;
@@ -92,6 +95,9 @@ void sip_lqr_group_destroy(sip_lqr_group *g) {
   for (hipEvent_t e : g->ready)
     if (e != nullptr)
       (void)hipEventDestroy(e);
+  for (hipEvent_t e : g->ready_done)
+    if (e != nullptr)
+      (void)hipEventDestroy(e);
   for (hipEvent_t e : g->landed)
     if (e != nullptr)
       (void)hipEventDestroy(e);
@@ -109,6 +115,8 @@ int sip_lqr_group_all_gather_gains(sip_lqr_group *g, const sip_lqr_plan *const *
   if (g == nullptr || plans == nullptr || d_gains == nullptr || d_all_gains == nullptr || streams == nullptr)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   const int n = (int)g->comms.size();
+  if (plans[0] == nullptr)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
   const size_t bytes = sip_lqr_gains_bytes(plans[0]);
   for (int i = 0; i < n; ++i)
     if (plans[i] == nullptr || sip_lqr_gains_bytes(plans[i]) != bytes || (bytes > 0 && (!d_gains[i] || !d_all_gains[i])))
@@ -181,6 +189,9 @@ int sip_lqr_all_gather_gains_chunk(const sip_lqr_plan *plan, void *nccl_comm, in
   if (nccl_comm == nullptr || nranks < 1 ||
       sip_lqr_gains_chunk_range(plan, chunk, num_chunks, &lo, &count) != SIP_LQR_OK)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
+  int comm_ranks = 0; // the chunk's place in the gathered buffer is derived from nranks: it must be the communicator's
+  if (ncclCommCount((ncclComm_t)nccl_comm, &comm_ranks) != ncclSuccess || comm_ranks != nranks)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
   const size_t per_problem = sip_lqr_gains_len(plan) * sip_lqr_scalar_bytes(plan);
   if (per_problem == 0 || count == 0)
     return SIP_LQR_OK;
@@ -200,7 +211,7 @@ int sip_lqr_group_all_gather_gains_chunk(sip_lqr_group *g, const sip_lqr_plan *c
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   const int n = (int)g->comms.size();
   int64_t lo = 0, count = 0;
-  if (sip_lqr_gains_chunk_range(plans[0], chunk, num_chunks, &lo, &count) != SIP_LQR_OK)
+  if (plans[0] == nullptr || sip_lqr_gains_chunk_range(plans[0], chunk, num_chunks, &lo, &count) != SIP_LQR_OK)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   const size_t bytes = sip_lqr_gains_bytes(plans[0]);
   for (int i = 0; i < n; ++i)
@@ -232,46 +243,67 @@ int sip_lqr_group_all_gather_gains_chunk(sip_lqr_group *g, const sip_lqr_plan *c
   return e == ncclSuccess ? SIP_LQR_OK : fail("sip_lqr_group_all_gather_gains_chunk(ncclGroupEnd)", e);
 }
 
-int sip_lqr_group_all_gather_gains_p2p(sip_lqr_group *g, const sip_lqr_plan *const *plans,
-                                       const void *const *d_gains, void *const *d_all_gains,
-                                       void *const *streams) {
+int sip_lqr_group_all_gather_gains_p2p_chunk(sip_lqr_group *g, const sip_lqr_plan *const *plans,
+                                             const void *const *d_gains, void *const *d_all_gains, int chunk,
+                                             int num_chunks, void *const *streams, void *const *done_streams) {
   if (g == nullptr || plans == nullptr || d_gains == nullptr || d_all_gains == nullptr || streams == nullptr)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   if (!g->peer_ok)
     return SIP_LQR_ERR_UNSUPPORTED;
   const int n = (int)g->devices.size();
+  int64_t lo = 0, count = 0;
+  if (plans[0] == nullptr || sip_lqr_gains_chunk_range(plans[0], chunk, num_chunks, &lo, &count) != SIP_LQR_OK)
+    return SIP_LQR_ERR_INVALID_ARGUMENT;
   const size_t bytes = sip_lqr_gains_bytes(plans[0]);
   for (int i = 0; i < n; ++i)
     if (plans[i] == nullptr || sip_lqr_gains_bytes(plans[i]) != bytes || (bytes > 0 && (!d_gains[i] || !d_all_gains[i])))
       return SIP_LQR_ERR_INVALID_ARGUMENT;
-  if (bytes == 0)
+  const size_t per_problem = sip_lqr_gains_len(plans[0]) * sip_lqr_scalar_bytes(plans[0]);
+  const size_t chunk_bytes = (size_t)count * per_problem;
+  if (chunk_bytes == 0)
     return SIP_LQR_OK;
+  if (done_streams == nullptr)
+    done_streams = streams;
   int prev_device = -1;
   (void)hipGetDevice(&prev_device);
   hipError_t e = hipSuccess;
-  for (int i = 0; i < n && e == hipSuccess; ++i) { // what rank i has enqueued so far produces its shard
+  // What rank i has enqueued so far on streams[i] produces its chunk; what it has enqueued on
+  // done_streams[i] may still read the gathered buffer the copies are about to overwrite.
+  for (int i = 0; i < n && e == hipSuccess; ++i) {
     e = hipSetDevice(g->devices[i]);
     if (e == hipSuccess)
       e = hipEventRecord(g->ready[i], (hipStream_t)streams[i]);
+    if (e == hipSuccess)
+      e = hipEventRecord(g->ready_done[i], (hipStream_t)done_streams[i]);
   }
   for (int i = 0; i < n && e == hipSuccess; ++i) { // source rank i: one copy per destination, all at once
     e = hipSetDevice(g->devices[i]);
+    const char *src = (const char *)d_gains[i] + (size_t)lo * per_problem;
     for (int j = 0; j < n && e == hipSuccess; ++j) {
       const hipStream_t ps = g->pair_streams[(size_t)i * n + j];
+      char *dst = (char *)d_all_gains[j] + sip_lqr_gains_chunk_offset(plans[0], n, i, chunk, num_chunks);
       e = hipStreamWaitEvent(ps, g->ready[i], 0);
-      if (e == hipSuccess && j != i) // the destination may still be read by what rank j has enqueued
+      if (e == hipSuccess) // the destination may still be read / written by what rank j has enqueued
+        e = hipStreamWaitEvent(ps, g->ready_done[j], 0);
+      if (e == hipSuccess && j != i)
         e = hipStreamWaitEvent(ps, g->ready[j], 0);
       if (e == hipSuccess)
-        e = hipMemcpyPeerAsync((char *)d_all_gains[j] + (size_t)i * bytes, g->devices[j], d_gains[i], g->devices[i],
-                               bytes, ps);
+        e = hipMemcpyPeerAsync(dst, g->devices[j], src, g->devices[i], chunk_bytes, ps);
       if (e == hipSuccess)
         e = hipEventRecord(g->landed[(size_t)i * n + j], ps);
     }
   }
-  for (int j = 0; j < n && e == hipSuccess; ++j) { // rank j's stream continues once everything has landed on j
-    e = hipSetDevice(g->devices[j]);
-    for (int i = 0; i < n && e == hipSuccess; ++i)
-      e = hipStreamWaitEvent((hipStream_t)streams[j], g->landed[(size_t)i * n + j], 0);
+  // done_streams[r] continues once everything has landed ON r (column r of the event matrix: the
+  // gathered chunk is complete) and every copy OUT of r has read its source (row r: d_gains[r] may be
+  // rewritten).  With done_streams == streams that is ncclAllGather's stream semantics: both buffers
+  // are safe to reuse behind the call.
+  for (int r = 0; r < n && e == hipSuccess; ++r) {
+    e = hipSetDevice(g->devices[r]);
+    for (int q = 0; q < n && e == hipSuccess; ++q) {
+      e = hipStreamWaitEvent((hipStream_t)done_streams[r], g->landed[(size_t)q * n + r], 0);
+      if (e == hipSuccess && q != r)
+        e = hipStreamWaitEvent((hipStream_t)done_streams[r], g->landed[(size_t)r * n + q], 0);
+    }
   }
   if (prev_device >= 0)
     (void)hipSetDevice(prev_device);
@@ -280,6 +312,13 @@ int sip_lqr_group_all_gather_gains_p2p(sip_lqr_group *g, const sip_lqr_plan *con
     return SIP_LQR_ERR_HIP;
   }
   return SIP_LQR_OK;
+}
+
+int sip_lqr_group_all_gather_gains_p2p(sip_lqr_group *g, const sip_lqr_plan *const *plans,
+                                       const void *const *d_gains, void *const *d_all_gains,
+                                       void *const *streams) {
+  // one chunk of one: chunk-major and rank-major layouts coincide
+  return sip_lqr_group_all_gather_gains_p2p_chunk(g, plans, d_gains, d_all_gains, 0, 1, streams, nullptr);
 }
 
 } // extern "C"

@@ -17,6 +17,15 @@ order 0 .. chunks-1 whatever the order in which the chunks became ready (each
 waits for its own event).  On CPU tensors (gloo; the tests) the same object
 runs with asynchronous work handles instead of streams.
 
+Two forms of the exchange (`mode`):
+  "allgather"  one `all_gather_into_tensor` per chunk (RCCL picks the algorithm: a ring pushes every
+               shard through one xGMI link seven times);
+  "mesh"       per chunk one `batch_isend_irecv` of world-1 sends of the local slice and world-1
+               receives straight into the gathered buffer: every rank talks to every peer at once, so
+               the seven xGMI links of a GPU each carry one copy of its slice (full
+               mesh, shard_bytes / link bandwidth), in one RCCL group per chunk, no extra memory.
+Both fill the same layout.
+
 Layout of the gathered gains: chunk-major, `gathered[c][r]` = rows of rank r's
 chunk c (what one ncclAllGather per chunk produces without any re-packing);
 `rows_of(rank, chunk)` / `problem(global_index)` address it.
@@ -45,8 +54,14 @@ def chunk_bounds(local_batch, chunks):
 class GainsAllGather:
     """Double-buffered, stream-pipelined, chunked all-gather of per-rank gains."""
 
-    def __init__(self, local_batch, gains_len, dtype, device, group=None, depth=2, chunks=1):
+    MODES = ("allgather", "mesh")
+
+    def __init__(self, local_batch, gains_len, dtype, device, group=None, depth=2, chunks=1, mode="allgather"):
+        if mode not in self.MODES:
+            raise ValueError(f"mode must be one of {self.MODES}")
+        self.mode = mode
         self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device)
         self.depth = depth
@@ -133,23 +148,51 @@ class GainsAllGather:
             torch.cuda.current_stream(self.device).synchronize()
             for c, (lo, hi) in enumerate(self.bounds):
                 host = torch.empty(self.world * (hi - lo), self.gains_len, dtype=out.dtype)
-                dist.all_gather_into_tensor(host, self.local[s][lo:hi].cpu(), group=self.group)
+                mine = self.local[s][lo:hi].cpu()
+                if self.mode == "mesh":
+                    for w in self._mesh_ops(mine, host.view(self.world, hi - lo, self.gains_len), own_copy=True):
+                        w.wait()
+                else:
+                    dist.all_gather_into_tensor(host, mine, group=self.group)
                 out[self.world * lo:self.world * hi].copy_(host)
         elif self.on_gpu:
             with torch.cuda.stream(self.comm_stream):
                 for c, (lo, hi) in enumerate(self.bounds):
                     self.comm_stream.wait_event(self._ready[s][c])
-                    dist.all_gather_into_tensor(out[self.world * lo:self.world * hi], self.local[s][lo:hi],
-                                                group=self.group)
+                    dst = out[self.world * lo:self.world * hi]
+                    if self.mode == "mesh":
+                        for w in self._mesh_ops(self.local[s][lo:hi], dst.view(self.world, hi - lo, self.gains_len),
+                                                own_copy=True):
+                            w.wait()   # stream-wise: the comm stream continues behind RCCL's group
+                    else:
+                        dist.all_gather_into_tensor(dst, self.local[s][lo:hi], group=self.group)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
             self._done[s] = done
         else:
             for c, (lo, hi) in enumerate(self.bounds):
-                self._work[s].append(dist.all_gather_into_tensor(out[self.world * lo:self.world * hi],
-                                                                 self.local[s][lo:hi], group=self.group,
-                                                                 async_op=True))
+                dst = out[self.world * lo:self.world * hi]
+                if self.mode == "mesh":
+                    self._work[s].extend(self._mesh_ops(self.local[s][lo:hi],
+                                                        dst.view(self.world, hi - lo, self.gains_len), own_copy=True))
+                else:
+                    self._work[s].append(dist.all_gather_into_tensor(dst, self.local[s][lo:hi], group=self.group,
+                                                                     async_op=True))
         return out
+
+    def _mesh_ops(self, mine, parts, own_copy):
+        """The full-mesh exchange of one chunk: `mine` ([rows, gains_len]) goes to every peer and peer
+        p's slice arrives in parts[p]; one batch (one RCCL group: all sends and receives progress
+        together, which is what lets the seven links work at the same time).  Returns the work handles."""
+        if own_copy:
+            parts[self.rank].copy_(mine)
+        glob = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
+        ops = []
+        for d in range(1, self.world):  # rank r sends to r + d while it receives from r - d
+            to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+            ops.append(dist.P2POp(dist.isend, mine, glob(to), self.group))
+            ops.append(dist.P2POp(dist.irecv, parts[frm], glob(frm), self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
 
     def wait(self, i):
         """Block (stream-wise on GPU) until the gathers of sweep i have landed."""

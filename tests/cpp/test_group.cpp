@@ -126,6 +126,62 @@ int main() {
       }
   }
   std::printf("direct peer copies and %d-chunk exchange ok\n", chunks);
+  // the caller's communicator form checks nranks against the communicator (it places the chunk by it)
+  // -- no communicator handle is public here, so only the argument checks that come first:
+  CHECK(sip_lqr_all_gather_gains_chunk(plans[0], nullptr, ndev, gains[0], all[0], 0, chunks, nullptr) ==
+        SIP_LQR_ERR_INVALID_ARGUMENT);
+  {
+    std::vector<const sip_lqr_plan *> null_plans(ndev, nullptr);
+    CHECK(sip_lqr_group_all_gather_gains(group, null_plans.data(), gains.data(), all.data(), streams.data()) ==
+          SIP_LQR_ERR_INVALID_ARGUMENT);
+    CHECK(sip_lqr_group_all_gather_gains_p2p(group, null_plans.data(), gains.data(), all.data(), streams.data()) ==
+          SIP_LQR_ERR_INVALID_ARGUMENT);
+  }
+  // Peer-copy exchange, chunk form, with completion streams of their own and the send buffer REUSED
+  // right behind the call (ncclAllGather's contract): the gains are overwritten on the done stream as
+  // soon as the call returns; the gathered data must still be the original.
+  {
+    std::vector<void *> done(ndev, nullptr);
+    for (int r = 0; r < ndev; ++r) {
+      hipStream_t st = nullptr;
+      CHECK(hipSetDevice(r) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+      done[r] = st;
+      CHECK(hipMemset(all[r], 0, gl * ndev * 8) == hipSuccess && hipDeviceSynchronize() == hipSuccess);
+    }
+    for (int c = 0; c < chunks; ++c)
+      CHECK(sip_lqr_group_all_gather_gains_p2p_chunk(group, plans.data(), gains.data(), all.data(), c, chunks,
+                                                     streams.data(), done.data()) == SIP_LQR_OK);
+    for (int r = 0; r < ndev; ++r) // rewrite the source behind the exchange, on the stream that waited for it
+      CHECK(hipSetDevice(r) == hipSuccess && hipMemsetAsync(gains[r], 0xff, gl * 8, (hipStream_t)done[r]) == hipSuccess);
+    for (int r = 0; r < ndev; ++r) {
+      CHECK(hipSetDevice(r) == hipSuccess && hipStreamSynchronize((hipStream_t)done[r]) == hipSuccess);
+      std::vector<double> got(gl * ndev);
+      CHECK(hipMemcpy(got.data(), all[r], gl * ndev * 8, hipMemcpyDeviceToHost) == hipSuccess);
+      for (int q = 0; q < ndev; ++q)
+        for (int c = 0; c < chunks; ++c) {
+          CHECK(sip_lqr_gains_chunk_range(plans[q], c, chunks, &lo, &cnt) == SIP_LQR_OK);
+          const size_t at = sip_lqr_gains_chunk_offset(plans[q], ndev, q, c, chunks) / 8;
+          CHECK(std::memcmp(got.data() + at, host_gains[q].data() + lo * per_problem, cnt * per_problem * 8) == 0);
+        }
+    }
+    for (int r = 0; r < ndev; ++r) { // restore, then the whole-shard form with the source rewritten on streams[r]
+      CHECK(hipSetDevice(r) == hipSuccess && hipDeviceSynchronize() == hipSuccess);
+      CHECK(hipMemcpy(gains[r], host_gains[r].data(), gl * 8, hipMemcpyHostToDevice) == hipSuccess);
+      CHECK(hipMemset(all[r], 0, gl * ndev * 8) == hipSuccess && hipDeviceSynchronize() == hipSuccess);
+    }
+    CHECK(sip_lqr_group_all_gather_gains_p2p(group, plans.data(), gains.data(), all.data(), done.data()) == SIP_LQR_OK);
+    for (int r = 0; r < ndev; ++r)
+      CHECK(hipSetDevice(r) == hipSuccess && hipMemsetAsync(gains[r], 0xff, gl * 8, (hipStream_t)done[r]) == hipSuccess);
+    for (int r = 0; r < ndev; ++r) {
+      CHECK(hipSetDevice(r) == hipSuccess && hipStreamSynchronize((hipStream_t)done[r]) == hipSuccess);
+      std::vector<double> got(gl * ndev);
+      CHECK(hipMemcpy(got.data(), all[r], gl * ndev * 8, hipMemcpyDeviceToHost) == hipSuccess);
+      for (int q = 0; q < ndev; ++q)
+        CHECK(std::memcmp(got.data() + q * gl, host_gains[q].data(), gl * 8) == 0);
+      CHECK(hipStreamDestroy((hipStream_t)done[r]) == hipSuccess);
+    }
+    std::printf("peer-copy exchange with completion streams and a reused send buffer ok\n");
+  }
   for (int r = 0; r < ndev; ++r)
     sip_lqr_plan_destroy(plans[r]);
   sip_lqr_group_destroy(group);

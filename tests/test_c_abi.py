@@ -214,7 +214,8 @@ def test_rccl_library_exports_its_header(lib):
     assert declared == {"sip_lqr_group_create", "sip_lqr_group_destroy", "sip_lqr_group_size",
                         "sip_lqr_group_all_gather_gains", "sip_lqr_all_gather_gains",
                         "sip_lqr_gains_chunk_range", "sip_lqr_gains_chunk_offset", "sip_lqr_all_gather_gains_chunk",
-                        "sip_lqr_group_all_gather_gains_chunk", "sip_lqr_group_all_gather_gains_p2p"}
+                        "sip_lqr_group_all_gather_gains_chunk", "sip_lqr_group_all_gather_gains_p2p",
+                        "sip_lqr_group_all_gather_gains_p2p_chunk"}
     out = __import__("subprocess").run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
     for name in declared:
         assert f" T {name}" in out, name

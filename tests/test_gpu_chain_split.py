@@ -108,3 +108,25 @@ def test_split_at_the_headline_size():
     u_ref = torch.einsum("btcj,btc->btj", K, x) + k
     scale = u.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1.0)
     assert float(((u - u_ref).abs() / scale).max()) <= 1e-9
+
+
+def test_split_rejects_problem_strides_beyond_32_bit_offsets():
+    """The four problems of a wavefront are addressed by 32-bit byte offsets from the first one's A | B
+    (include/sip_lqr_amd.h): a larger stride is an error, not a silent wrap."""
+    import ctypes
+    n, m, T, batch = 12, 4, 3, 4
+    solver, mats, vecs = _problem(n, m, T, batch, seed=9)
+    if not solver.has_split:
+        pytest.skip("no split kernel")
+    qmr, ab = solver.split_inputs(mats)
+    sol, gains = solver.empty_sol(), solver.empty_gains()
+    args = lambda stride: (solver._plan, ctypes.c_void_p(qmr.data_ptr()), ctypes.c_void_p(ab.data_ptr()),
+                           ctypes.c_int64(stride), ctypes.c_int64(ab.stride(1)), ctypes.c_void_p(vecs.data_ptr()),
+                           ctypes.c_void_p(sol.data_ptr()), ctypes.c_void_p(gains.data_ptr()),
+                           ctypes.c_void_p(solver.status.data_ptr()), ctypes.c_void_p(solver.workspace.data_ptr()),
+                           ctypes.c_void_p(0))
+    limit = ((1 << 32) - 1 - 8 * n * (n + m)) // 24
+    assert solver._lib.sip_lqr_factor_solve_split(*args(limit + 2)) == -1   # SIP_LQR_ERR_INVALID_ARGUMENT
+    assert solver._lib.sip_lqr_factor_solve_split(*args(1 << 29)) == -1
+    assert solver._lib.sip_lqr_factor_solve_split(*args(ab.stride(0))) == 0
+    torch.cuda.synchronize()

@@ -46,12 +46,12 @@ def _fake_gains(rank, step, local_batch, gains_len):
     return torch.from_numpy(base + 1000.0 * rank + 1e6 * step)
 
 
-def _worker(rank, world, port, local_batch, gains_len, steps, chunks, out):
+def _worker(rank, world, port, local_batch, gains_len, steps, chunks, mode, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ag = GainsAllGather(local_batch, gains_len, torch.float64, "cpu", chunks=chunks)
+        ag = GainsAllGather(local_batch, gains_len, torch.float64, "cpu", chunks=chunks, mode=mode)
         results = []
         for i in range(steps):
             buf = ag.acquire(i)
@@ -82,15 +82,16 @@ def _worker(rank, world, port, local_batch, gains_len, steps, chunks, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["allgather", "mesh"])
 @pytest.mark.parametrize("world,local_batch,chunks", [(2, 5, 1), (2, 8, 4), (4, 7, 3), (4, 16, 8)])
-def test_gains_all_gather_gloo(world, local_batch, chunks):
+def test_gains_all_gather_gloo(world, local_batch, chunks, mode):
     gains_len, steps = 52, 5
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, local_batch, gains_len, steps, chunks, out))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, local_batch, gains_len, steps, chunks, mode, out))
              for r in range(world)]
     for p in procs:
         p.start()
