@@ -1,0 +1,693 @@
+// chain_mt16.hpp -- batched chain Riccati kernel for n = 32 on 16 x 16 matrix-core tiles
+// (BASELINE config 4: batch 4096, T = 100, n = 32, m = 8, fp32; the same code in fp64).
+//
+// One problem per wavefront.  A 32 x 32 matrix is 2 x 2 tiles in the C/D layout of
+// v_mfma_{f32,f64}_16x16x4: lane (j = lane & 15, g = lane >> 4), register v of tile (I, J) holds
+// element (16 I + row(g, v), 16 J + j), row(g, v) = 4 g + v in fp32 and g + 4 v in fp64.  In that layout
+//
+//      sum_v mfma(U[v], V[v]) = U^T V            (one 16 x 16 tile, contraction over the tile's rows)
+//
+// takes both operands as they stand (register v of lane (j, g) is A[i = j][k = g] of one operand and
+// B[k = g][j] of the other), so no operand of the recursion ever goes through LDS:
+//      F = W A = W^T A                         lqr.cpp:703          32 MFMAs
+//      Z = W B                                 (H_child^T, :692)     16
+//      G = R + B^T Z                           lqr.cpp:693-694        8
+//      H = M^T + B^T F                         lqr.cpp:704-705       16
+//      K = -G^-1 H                             lqr.cpp:707-713        4
+//      V = Q + A^T F + K^T H                   lqr.cpp:715-719       32 + 8
+// Against the 32x32x2 formulation of chain_mf32.hpp the m-row blocks (Z, G, H, K: 8 of 32 rows or
+// columns) cost a 16-wide tile instead of a 32-wide one.  Controls sit at the tile rows / columns
+// row(a & 3, a >> 2): registers 0 and 1 of every lane group, so a contraction over the control index
+// (K = Gn^T H, K^T H) issues two MFMAs per tile, not four.
+//
+// The factorisations are symmetric SWEEPS on the matrix pipe, four pivots per step: with K the pivot
+// set, C = A[:, K], P = A[K, K],
+//      A[i][j] <- A[i][j] - C_i P^-1 C_j^T  (i, j not in K),  A[:, K] <- C P^-1,  A[K, K] <- -P^-1,
+// and after all pivots A holds -A^-1 (the sweep operator).  The pivots met on the way are the Schur
+// complements a Cholesky meets (d_k = L_kk^2 of Eigen::LLT, lqr.cpp:505 / :697, in this pivot order),
+// so "pivot <= 0" <=> the reference's failure status.  One sweep replaces Cholesky + triangular
+// inverse + X^T X of chain_mf32.hpp (48 MFMAs of 32x32x2 -> the equivalent of 24), and W follows as
+// W = D^-1/2 (I - F^-1) D^-1/2 (lqr.cpp:521-528) elementwise.  The pivot set of a step is register v of
+// the four lane groups (rows row(0..3, v) of tile row I): then C^T is register v of tile row I AS IT
+// STANDS for both operands of the update
+//      A += (-C + [I on the pivot rows]) * (P^-1 (C^T - [I on the pivot columns])),
+// whose modified operands also write the pivot rows and columns (C P^-1) and leave 2 I - P^-1 on the
+// pivot block (corrected by a subtraction on four lanes).  P^-1 (4 x 4, from an LDL^T in registers,
+// uniform over the wave) enters through one more MFMA per tile column ("mix").
+//
+// Vectors (g, h, k, v of the affine sweep; x, u, y of the rollout) are small LDS arrays and
+// broadcast-FMA sums over the lane groups.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sipamd {
+namespace mt16 {
+
+constexpr int N = 32;
+
+template <typename S> struct Tr;
+template <> struct Tr<float> {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  static constexpr bool ROWS_CONTIGUOUS = true; // registers 0..3 of a lane are consecutive rows
+  static __device__ __forceinline__ constexpr int row(const int g, const int v) { return 4 * g + v; }
+  static __device__ __forceinline__ v4 mfma(const float a, const float b, const v4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float rcp(const float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r); // one Newton step: < 1 ulp
+  }
+  static __device__ __forceinline__ float uniform(const float x, const int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+  }
+  static __device__ __forceinline__ float sqrt(const float x) { return sqrtf(x); }
+  static __device__ __forceinline__ float rsqrt(const float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float fma(const float a, const float b, const float c) { return __builtin_fmaf(a, b, c); }
+};
+template <> struct Tr<double> {
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  static constexpr bool ROWS_CONTIGUOUS = false;
+  static __device__ __forceinline__ constexpr int row(const int g, const int v) { return g + 4 * v; }
+  static __device__ __forceinline__ v4 mfma(const double a, const double b, const v4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ double rcp(const double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double uniform(const double x, const int lane) {
+    const long long bits = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+  static __device__ __forceinline__ double sqrt(const double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double rsqrt(const double x) { return 1.0 / ::sqrt(x); }
+  static __device__ __forceinline__ double fma(const double a, const double b, const double c) { return __builtin_fma(a, b, c); }
+};
+
+// typed fused multiply-add (__builtin_fma on floats would go through double)
+__device__ __forceinline__ float fma_(const float a, const float b, const float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(const double a, const double b, const double c) { return __builtin_fma(a, b, c); }
+
+template <typename S> struct Mat32 { // 32 x 32: t[I][J]
+  typename Tr<S>::v4 t[2][2];
+};
+template <typename S> struct Pair { // 32 x 16 (t[I]: B, Z) or 16 x 32 (t[J]: H, K, M^T)
+  typename Tr<S>::v4 t[2];
+};
+
+template <typename S> __device__ __forceinline__ typename Tr<S>::v4 zero4() {
+  return typename Tr<S>::v4{S(0), S(0), S(0), S(0)};
+}
+
+// acc += U^T V (32 x 32 each); four independent accumulators take turns (the 16x16x4 MFMA has a
+// 40-cycle dependent latency against a 32-cycle issue interval)
+template <typename S>
+__device__ __forceinline__ void mul_tt(const Mat32<S> &U, const Mat32<S> &V, Mat32<S> &acc) {
+#pragma unroll
+  for (int R = 0; R < 2; ++R)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+          acc.t[I][J] = Tr<S>::mfma(U.t[R][I][v], V.t[R][J][v], acc.t[I][J]);
+}
+
+// Position of the lane and the control index of a tile row / column.
+template <typename S> struct LaneT {
+  int lane, j, g;
+  S eg[4]; // one-hot of the lane group:      eg[k] = (g == k)
+  S ej[4]; // one-hot of the tile rows row(kk, 0): ej[kk] = (j == row(kk, 0))
+};
+// control index of tile row row(g, v): a = g + 4 v
+__device__ __forceinline__ constexpr int ctrl_of(const int g, const int v) { return g + 4 * v; }
+// control index of tile COLUMN j (the (g', v') with row(g', v') == j)
+template <typename S> __device__ __forceinline__ int ctrl_of_col(const int j) {
+  return Tr<S>::ROWS_CONTIGUOUS ? (j >> 2) + 4 * (j & 3) : j;
+}
+
+// sum over the four lane groups (lanes j, j + 16, j + 32, j + 48): every lane gets the total
+template <typename S> __device__ __forceinline__ S sum_groups(S x) {
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+// vec[16 I + row(g, v)], v = 0..3 (LDS array indexed by row)
+template <typename S>
+__device__ __forceinline__ typename Tr<S>::v4 by_row(const S *vec, const int I, const int g) {
+  typename Tr<S>::v4 r;
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+    r[v] = vec[16 * I + Tr<S>::row(g, v)];
+  return r;
+}
+
+// y = Mt^T vec: returns the partial sums of this lane group for columns j and 16 + j (sum_groups
+// completes them); vec given by row.
+template <typename S>
+__device__ __forceinline__ void mat_t_vec(const Mat32<S> &Mt, const typename Tr<S>::v4 (&xr)[2], S &p0, S &p1) {
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      p0 = fma_(Mt.t[I][0][v], xr[I][v], p0);
+      p1 = fma_(Mt.t[I][1][v], xr[I][v], p1);
+    }
+}
+
+// ---- the sweep -------------------------------------------------------------------------------
+// T: TILES x TILES symmetric matrix in tiles; sweeps the pivots of registers 0 .. VP-1 of every tile
+// row (all of them for VP = 4).  Returns true iff a pivot was <= 0.  On return the swept rows and
+// columns hold -A^-1 restricted to them (all of -A^-1 for VP = 4).
+template <typename S, int TILES, int VP>
+__device__ __forceinline__ bool sweep(typename Tr<S>::v4 (&T)[TILES][TILES], const LaneT<S> &L) {
+  using TR = Tr<S>;
+  using v4 = typename TR::v4;
+  bool fail = false;
+#pragma unroll
+  for (int I = 0; I < TILES; ++I) {
+#pragma unroll
+    for (int v = 0; v < VP; ++v) {
+      // P[a][b] = A[p_a][p_b], p_g = 16 I + row(g, v): register v of lane (j = row(b, v), g = a)
+      S P[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b)
+          P[a][b] = TR::uniform(T[I][I][v], 16 * a + TR::row(b, v));
+      // LDL^T of P: the pivots d_k are those of an unblocked Cholesky (squared)
+      const S d0 = P[0][0], i0 = TR::rcp(d0);
+      const S l10 = P[1][0] * i0, l20 = P[2][0] * i0, l30 = P[3][0] * i0;
+      const S d1 = fma_(-l10, P[1][0], P[1][1]), i1 = TR::rcp(d1);
+      const S t21 = fma_(-l20, P[1][0], P[2][1]), t31 = fma_(-l30, P[1][0], P[3][1]);
+      const S l21 = t21 * i1, l31 = t31 * i1;
+      const S d2 = fma_(-l21, t21, fma_(-l20, P[2][0], P[2][2])), i2 = TR::rcp(d2);
+      const S t32 = fma_(-l31, t21, fma_(-l30, P[2][0], P[3][2]));
+      const S l32 = t32 * i2;
+      const S d3 = fma_(-l32, t32, fma_(-l31, t31, fma_(-l30, P[3][0], P[3][3])));
+      const S i3 = TR::rcp(d3);
+      fail |= !(d0 > S(0)) | !(d1 > S(0)) | !(d2 > S(0)) | !(d3 > S(0));
+      // M = L^-1 (unit lower), P^-1 = M^T D^-1 M.  Lane group g only needs column g of P^-1 (it is the
+      // k index of the mix's A operand): y = M^T D^-1 M e_g with the one-hot e_g of the lane group.
+      const S m10 = -l10, m21 = -l21, m32 = -l32;
+      const S m20 = fma_(l21, l10, -l20);
+      const S m31 = fma_(l32, l21, -l31);
+      const S m30 = fma_(-l32, m20, fma_(l31, l10, -l30));
+      const S t1 = fma_(m10, L.eg[0], L.eg[1]);
+      const S t2 = fma_(m20, L.eg[0], fma_(m21, L.eg[1], L.eg[2]));
+      const S t3 = fma_(m30, L.eg[0], fma_(m31, L.eg[1], fma_(m32, L.eg[2], L.eg[3])));
+      const S w0 = i0 * L.eg[0], w1 = i1 * t1, w2 = i2 * t2, w3 = i3 * t3;
+      const S y2 = fma_(m32, w3, w2);
+      const S y1 = fma_(m31, w3, fma_(m21, w2, w1));
+      const S y0 = fma_(m30, w3, fma_(m20, w2, fma_(m10, w1, w0)));
+      // A operand of the mix: P^-1[kk][kq] on lane (i = row(kk, 0), kq = g); its result lands in register 0
+      // of lane group kk, where the update wants its B operand
+      const S amix = fma_(L.ej[0], y0, fma_(L.ej[1], y1, fma_(L.ej[2], y2, L.ej[3] * w3)));
+      const bool diag = L.j == TR::row(L.g, v); // this lane's register v of tile (I, I) is a diagonal element
+      const S one_d = diag ? S(1) : S(0);
+      S bop[TILES], aop[TILES];
+#pragma unroll
+      for (int Jt = 0; Jt < TILES; ++Jt) {
+        const S src = T[I][Jt][v] - (Jt == I ? one_d : S(0));
+        aop[Jt] = -src; // tile (I, Jt) register v is also -C^T of output tile row Jt
+        const v4 mixed = TR::mfma(amix, src, zero4<S>());
+        bop[Jt] = mixed[0];
+      }
+#pragma unroll
+      for (int It = 0; It < TILES; ++It)
+#pragma unroll
+        for (int Jt = 0; Jt < TILES; ++Jt)
+          T[It][Jt] = TR::mfma(aop[It], bop[Jt], T[It][Jt]);
+      T[I][I][v] -= S(2) * one_d;
+    }
+  }
+  return fail;
+}
+
+template <typename S, int M> struct Layout {
+  static constexpr int NODE = N * N + N;                 // Q | delta
+  static constexpr int EDGE = N * N + 2 * N * M + M * M; // A | B | M | R
+  static constexpr int VNODE = 2 * N, VEDGE = M, GAIN = M * N + M;
+  static constexpr int WSN = N * N + N; // W (tile dump) | g
+  static constexpr int VM = (M + 3) / 4; // registers of a lane that hold controls
+  // 16-byte loads of four consecutive rows need every block 16-byte aligned
+  static constexpr bool VEC_LOADS = Tr<S>::ROWS_CONTIGUOUS && (EDGE % 4 == 0);
+};
+
+// Column-major 32 x 32 (ld 32) -> tiles.
+template <typename S, bool VEC>
+__device__ __forceinline__ Mat32<S> load32(const S *m, const LaneT<S> &L) {
+  using v4 = typename Tr<S>::v4;
+  Mat32<S> r;
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 2; ++J) {
+      const S *col = m + (16 * J + L.j) * N + 16 * I;
+      if constexpr (VEC) {
+        r.t[I][J] = *(const v4 *)(col + 4 * L.g);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          r.t[I][J][v] = col[Tr<S>::row(L.g, v)];
+      }
+    }
+  return r;
+}
+
+template <typename S, int M>
+__global__ __launch_bounds__(64) void chain_factor_solve_mt16(
+    const S *__restrict__ mats, const S *__restrict__ vecs, S *__restrict__ sol, S *__restrict__ gains,
+    S *__restrict__ wsp, int *__restrict__ status, const long batch, const int T) {
+  static_assert(M >= 1 && M <= 8, "controls live in registers 0 and 1 of the four lane groups");
+  using TR = Tr<S>;
+  using v4 = typename TR::v4;
+  using LY = Layout<S, M>;
+  constexpr int STG = LY::NODE + LY::EDGE, VSTG = LY::VNODE + LY::VEDGE, VM = LY::VM;
+  constexpr bool VEC = LY::VEC_LOADS;
+  const long p = blockIdx.x;
+  if (p >= batch)
+    return;
+  LaneT<S> L;
+  L.lane = threadIdx.x & 63, L.j = L.lane & 15, L.g = L.lane >> 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    L.eg[k] = L.g == k ? S(1) : S(0);
+    L.ej[k] = L.j == TR::row(k, 0) ? S(1) : S(0);
+  }
+  const int j = L.j, g = L.g;
+  const int acol = ctrl_of_col<S>(j); // control index of this lane's tile column (valid if < M)
+  const S *pm = mats + p * ((long)(T + 1) * LY::NODE + (long)T * LY::EDGE);
+  const S *pv = vecs + p * ((long)(T + 1) * LY::VNODE + (long)T * LY::VEDGE);
+  S *ps = sol + p * ((long)(T + 1) * LY::VNODE + (long)T * LY::VEDGE);
+  S *pg = gains + p * ((long)T * LY::GAIN);
+  S *pw = wsp + p * ((long)(T + 1) * LY::WSN);
+
+  __shared__ S s_v[N], s_t[N], s_g[N], s_sd[N], s_sdi[N], s_x[N], s_z[N], s_gs[16], s_h[8], s_u[8];
+  constexpr int LDM = TR::ROWS_CONTIGUOUS ? 36 : 33; // column stride of the mirror image (bank spread; 16-byte columns)
+  __shared__ __attribute__((aligned(16))) S s_m[N * LDM];
+
+  if (L.lane < 8)
+    s_h[L.lane] = S(0), s_u[L.lane] = S(0); // the entries of no control are read as zeros
+  int stat = 0;
+  Mat32<S> W, V;
+
+  // ---- node tail: F = I + D^1/2 V D^1/2, its sweep, W (lqr.cpp:487-529, 722-727), plus the vector
+  // term t = c - delta o v for the parent step.
+  auto finish_node = [&](const int i) {
+    const S *nm = pm + (long)i * STG;
+    const S *nv = pv + (long)i * VSTG;
+    const S dl0 = nm[N * N + j], dl1 = nm[N * N + 16 + j];
+    if (stat == 0 && __any(!(dl0 > S(0)) || !(dl1 > S(0))))
+      stat = 1; // INVALID_DELTA
+    const S sd0 = TR::sqrt(dl0), sd1 = TR::sqrt(dl1);
+    const S sdi0 = S(1) / sd0, sdi1 = S(1) / sd1;
+    if (g == 0) {
+      s_sd[j] = sd0, s_sd[16 + j] = sd1;
+      s_sdi[j] = sdi0, s_sdi[16 + j] = sdi1;
+      s_t[j] = nv[N + j] - dl0 * s_v[j]; // c - delta o v   (lqr.cpp:778-779, negated)
+      s_t[16 + j] = nv[N + 16 + j] - dl1 * s_v[16 + j];
+    }
+    // Only the lower triangle of V counts (Eigen::LLT reads nothing else, lqr.cpp:505): mirror it through
+    // LDS.  V = Q + A^T F + K^T H is symmetric only up to rounding, the sweep reads rows as columns, and the
+    // recursion does not damp an antisymmetric part (the feedback term K^T H is symmetric by construction):
+    // left alone it grows by |A|^2 per stage.
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J) { // tile (0, 1) is not read back
+        S *col = s_m + (16 * J + j) * LDM + 16 * I;
+        if constexpr (TR::ROWS_CONTIGUOUS) {
+          *(v4 *)(col + 4 * g) = V.t[I][J];
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            col[TR::row(g, v)] = V.t[I][J][v];
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = I; J < 2; ++J)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * I + TR::row(g, v), c = 16 * J + j;
+          const S mirrored = s_m[r * LDM + c]; // element (c, r)
+          V.t[I][J][v] = (J > I || r < c) ? mirrored : V.t[I][J][v];
+        }
+    // F = I + sd V sd (lqr.cpp:497-503), in place
+    {
+      const v4 sr[2] = {by_row<S>(s_sd, 0, g), by_row<S>(s_sd, 1, g)};
+#pragma unroll
+      for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const bool dg = I == J && j == TR::row(g, v);
+            V.t[I][J][v] = fma_(V.t[I][J][v] * sr[I][v], J == 0 ? sd0 : sd1, dg ? S(1) : S(0));
+          }
+    }
+    const bool ffail = sweep<S, 2, 4>(V.t, L); // V now holds -F^-1
+    if (stat == 0 && ffail)
+      stat = 2; // F_FACTORIZATION_FAILURE
+    // W = D^-1/2 (I - F^-1) D^-1/2
+    {
+      const v4 ir[2] = {by_row<S>(s_sdi, 0, g), by_row<S>(s_sdi, 1, g)};
+#pragma unroll
+      for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const bool dg = I == J && j == TR::row(g, v);
+            W.t[I][J][v] = (V.t[I][J][v] + (dg ? S(1) : S(0))) * (ir[I][v] * (J == 0 ? sdi0 : sdi1));
+          }
+    }
+    // spill W (tile dump) for the rollout
+    v4 *wd = (v4 *)(pw + (long)i * LY::WSN);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+        wd[(2 * I + J) * 64 + L.lane] = W.t[I][J];
+    __syncthreads();
+  };
+
+  // ---- terminal node -------------------------------------------------------------------------
+  V = load32<S, VEC>(pm + (long)T * STG, L);
+  if (g == 0) {
+    s_v[j] = pv[(long)T * VSTG + j]; // v = q
+    s_v[16 + j] = pv[(long)T * VSTG + 16 + j];
+  }
+  __syncthreads();
+  finish_node(T);
+
+  // ---- backward recursion --------------------------------------------------------------------
+  for (int i = T - 1; i >= 0; --i) {
+    const S *nm = pm + (long)i * STG;
+    const S *em = nm + LY::NODE;
+    const S *nv = pv + (long)i * VSTG;
+    const S *Bm = em + N * N, *Mm = Bm + N * M, *Rm = Mm + N * M;
+    const Mat32<S> A = load32<S, VEC>(em, L);
+    // B (32 x M, ld 32): control acol on tile column j; columns of no control are zero
+    Pair<S> B;
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+      const S *col = Bm + (acol < M ? acol : 0) * N + 16 * I;
+      if constexpr (VEC) {
+        B.t[I] = *(const v4 *)(col + 4 * g);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          B.t[I][v] = col[TR::row(g, v)];
+      }
+      if (acol >= M)
+        B.t[I] = zero4<S>();
+    }
+    // H starts as M^T (row = control ctrl_of(g, v), column 16 J + j), G as R with an identity on the
+    // rows / columns of no control
+    Pair<S> H;
+    v4 G;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int a = ctrl_of(g, v);
+      const bool ok = v < VM && a < M;
+      if (v < VM) { // unconditional loads from clamped addresses, then a select (no branches)
+        const int ac = ok ? a : 0, cc = acol < M ? acol : 0;
+        const S h0 = Mm[ac * N + j], h1 = Mm[ac * N + 16 + j], rr = Rm[cc * M + ac];
+        H.t[0][v] = ok ? h0 : S(0);
+        H.t[1][v] = ok ? h1 : S(0);
+        G[v] = (ok && acol < M) ? rr : (j == TR::row(g, v) ? S(1) : S(0));
+      } else {
+        H.t[0][v] = S(0), H.t[1][v] = S(0);
+        G[v] = j == TR::row(g, v) ? S(1) : S(0);
+      }
+    }
+    // g = v_c + W t   (lqr.cpp:778-781)
+    {
+      const v4 tr[2] = {by_row<S>(s_t, 0, g), by_row<S>(s_t, 1, g)};
+      S w0 = S(0), w1 = S(0);
+      mat_t_vec<S>(W, tr, w0, w1);
+      const S g0 = s_v[j] + sum_groups(w0), g1 = s_v[16 + j] + sum_groups(w1);
+      if (g == 0) {
+        s_g[j] = g0, s_g[16 + j] = g1;
+        pw[(long)(i + 1) * LY::WSN + N * N + j] = g0;
+        pw[(long)(i + 1) * LY::WSN + N * N + 16 + j] = g1;
+      }
+    }
+    Mat32<S> F;
+    Pair<S> Z;
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+      Z.t[I] = zero4<S>();
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+        F.t[I][J] = zero4<S>();
+    }
+    // Z = W B and F = W A, interleaved: six independent accumulators
+#pragma unroll
+    for (int R = 0; R < 2; ++R)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+          Z.t[I] = TR::mfma(W.t[R][I][v], B.t[R][v], Z.t[I]);
+#pragma unroll
+          for (int J = 0; J < 2; ++J)
+            F.t[I][J] = TR::mfma(W.t[R][I][v], A.t[R][J][v], F.t[I][J]);
+        }
+    // G = R + B^T Z, H = M^T + B^T F
+#pragma unroll
+    for (int R = 0; R < 2; ++R)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        G = TR::mfma(B.t[R][v], Z.t[R][v], G);
+        H.t[0] = TR::mfma(B.t[R][v], F.t[R][0][v], H.t[0]);
+        H.t[1] = TR::mfma(B.t[R][v], F.t[R][1][v], H.t[1]);
+      }
+    __syncthreads(); // s_g
+    const v4 gr[2] = {by_row<S>(s_g, 0, g), by_row<S>(s_g, 1, g)};
+    // h = r + B^T g  (lqr.cpp:783-784): control acol on the lanes of tile column j
+    {
+      S pb = S(0);
+#pragma unroll
+      for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          pb = fma_(B.t[I][v], gr[I][v], pb);
+      pb = sum_groups(pb);
+      if (g == 0 && acol < M)
+        s_h[acol] = nv[LY::VNODE + acol] + pb;
+    }
+    // LLT of G (lqr.cpp:696-701) as a sweep: G <- -G^-1 on the control rows / columns.  The sweep's modified
+    // operands work against an identity on the pivot block, which costs accuracy when the pivots are far from
+    // 1 (G ~ R is not scaled like F = I + ...): sweep the unit-diagonal S G S, S = diag(G)^-1/2, and scale back.
+    {
+      S dsel = S(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        dsel += j == TR::row(g, v) ? G[v] : S(0);
+      const S sc = TR::rsqrt(sum_groups(dsel)); // of tile column j; NaN for a diagonal <= 0: the sweep then fails
+      if (g == 0)
+        s_gs[j] = sc;
+      __syncthreads();
+      const v4 sr = by_row<S>(s_gs, 0, g);
+      v4 Gt[1][1];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        Gt[0][0][v] = G[v] * (sr[v] * sc);
+      const bool gfail = sweep<S, 1, VM>(Gt, L);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        G[v] = Gt[0][0][v] * (sr[v] * sc);
+      if (stat == 0 && gfail)
+        stat = 3; // G_FACTORIZATION_FAILURE
+    }
+    // K = -G^-1 H   (lqr.cpp:707-713); -G^-1 symmetric
+    Pair<S> K;
+    K.t[0] = zero4<S>(), K.t[1] = zero4<S>();
+#pragma unroll
+    for (int v = 0; v < VM; ++v) {
+      K.t[0] = TR::mfma(G[v], H.t[0][v], K.t[0]);
+      K.t[1] = TR::mfma(G[v], H.t[1][v], K.t[1]);
+    }
+    __syncthreads(); // s_h
+    S hr[VM];
+#pragma unroll
+    for (int v = 0; v < VM; ++v)
+      hr[v] = s_h[ctrl_of(g, v)]; // entries >= M stay zero
+    // k = -G^-1 h   (lqr.cpp:785-791), control acol on tile column j
+    S kb = S(0);
+#pragma unroll
+    for (int v = 0; v < VM; ++v)
+      kb = fma_(G[v], hr[v], kb);
+    kb = sum_groups(kb);
+    // gains out: K (m x 32 column-major) | k
+    {
+      S *gi = pg + (long)i * LY::GAIN;
+#pragma unroll
+      for (int v = 0; v < VM; ++v)
+        if (ctrl_of(g, v) < M) {
+          gi[j * M + ctrl_of(g, v)] = K.t[0][v];
+          gi[(16 + j) * M + ctrl_of(g, v)] = K.t[1][v];
+        }
+      if (g == 0 && acol < M)
+        gi[M * N + acol] = kb;
+    }
+    // v = q + A^T g + K^T h   (lqr.cpp:793-794)
+    {
+      S p0 = S(0), p1 = S(0);
+      mat_t_vec<S>(A, gr, p0, p1);
+#pragma unroll
+      for (int v = 0; v < VM; ++v) {
+        p0 = fma_(K.t[0][v], hr[v], p0);
+        p1 = fma_(K.t[1][v], hr[v], p1);
+      }
+      const S vn0 = nv[j] + sum_groups(p0), vn1 = nv[16 + j] + sum_groups(p1);
+      __syncthreads(); // everyone is done with s_v / s_t / s_g of the child
+      if (g == 0)
+        s_v[j] = vn0, s_v[16 + j] = vn1;
+    }
+    // V = Q + A^T F + K^T H   (lqr.cpp:715-719)
+    V = load32<S, VEC>(nm, L);
+    mul_tt<S>(A, F, V);
+#pragma unroll
+    for (int v = 0; v < VM; ++v)
+#pragma unroll
+      for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+          V.t[I][J] = TR::mfma(K.t[I][v], H.t[J][v], V.t[I][J]);
+    __syncthreads();
+    finish_node(i);
+  }
+
+  // ---- root: g_0 = v_0 + W_0 t_0 ; x_0 = c_0 - delta_0 o g_0, y_0 = g_0 -----------------------
+  {
+    const v4 tr[2] = {by_row<S>(s_t, 0, g), by_row<S>(s_t, 1, g)};
+    S w0 = S(0), w1 = S(0);
+    mat_t_vec<S>(W, tr, w0, w1);
+    const S g0 = s_v[j] + sum_groups(w0), g1 = s_v[16 + j] + sum_groups(w1);
+    if (g == 0) {
+      const S x0 = pv[N + j] - pm[N * N + j] * g0, x1 = pv[N + 16 + j] - pm[N * N + 16 + j] * g1;
+      ps[j] = x0, ps[16 + j] = x1;
+      ps[N + j] = g0, ps[N + 16 + j] = g1;
+      s_x[j] = x0, s_x[16 + j] = x1;
+    }
+  }
+  if (L.lane == 0)
+    status[p] = stat;
+  __syncthreads();
+
+  // ---- forward rollout (lqr.cpp:821-870) -----------------------------------------------------
+  // The products sum over the rows of the tile, so the operands are loaded transposed (K^T, A^T, B^T:
+  // rows = the index summed over); W is symmetric.  Nothing a stage reads from memory depends on x:
+  // every operand of stage i + 1 is requested as soon as stage i has used the registers it lands in
+  // (one register set, a stage of lead time).
+  Pair<S> KT;   // t[I]: K^T rows 16 I + row(g, v), control acol
+  Mat32<S> AT;  // A^T
+  Pair<S> BT;   // t[J]: B^T rows = controls (registers < VM), columns 16 J + j
+  Mat32<S> Wc;  // W of the child
+  S kb, gc0, gc1, cc0, cc1, dc0, dc1;
+  auto fetch_K = [&](const int i) {
+    const S *gi = pg + (long)i * LY::GAIN;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        KT.t[I][v] = gi[(16 * I + TR::row(g, v)) * M + (acol < M ? acol : 0)]; // K(acol, r); other lanes: unused
+    kb = gi[M * N + (acol < M ? acol : 0)];
+  };
+  auto fetch_AB = [&](const int i) {
+    const S *em = pm + (long)i * STG + LY::NODE;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 16 * I + TR::row(g, v);
+        AT.t[I][0][v] = em[r * N + j]; // A(j, r)
+        AT.t[I][1][v] = em[r * N + 16 + j];
+      }
+#pragma unroll
+    for (int v = 0; v < VM; ++v) {
+      const int a = ctrl_of(g, v), ac = a < M ? a : 0;
+      const S b0 = em[N * N + ac * N + j], b1 = em[N * N + ac * N + 16 + j]; // B(j, a)
+      BT.t[0][v] = a < M ? b0 : S(0);
+      BT.t[1][v] = a < M ? b1 : S(0);
+    }
+  };
+  auto fetch_W = [&](const int i) { // the child's W, g and the node vectors of the child
+    const S *nm1 = pm + (long)(i + 1) * STG;
+    const S *nv1 = pv + (long)(i + 1) * VSTG;
+    const S *wn = pw + (long)(i + 1) * LY::WSN;
+    const v4 *wd = (const v4 *)wn;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+        Wc.t[I][J] = wd[(2 * I + J) * 64 + L.lane];
+    gc0 = wn[N * N + j], gc1 = wn[N * N + 16 + j];
+    cc0 = nv1[N + j], cc1 = nv1[N + 16 + j];
+    dc0 = nm1[N * N + j], dc1 = nm1[N * N + 16 + j];
+  };
+  if (T > 0) {
+    fetch_K(0);
+    fetch_AB(0);
+    fetch_W(0);
+  }
+  for (int i = 0; i < T; ++i) {
+    const bool more = i + 1 < T;
+    const v4 xr[2] = {by_row<S>(s_x, 0, g), by_row<S>(s_x, 1, g)};
+    // u = k + K x : control acol on tile column j
+    S pu = S(0);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        pu = fma_(KT.t[I][v], xr[I][v], pu);
+    const S ub = kb + sum_groups(pu);
+    if (more)
+      fetch_K(i + 1);
+    if (g == 0 && acol < M)
+      s_u[acol] = ub;
+    __syncthreads();
+    // z = A x + B u
+    S z0 = S(0), z1 = S(0);
+    mat_t_vec<S>(AT, xr, z0, z1);
+#pragma unroll
+    for (int v = 0; v < VM; ++v) {
+      const S ur = s_u[ctrl_of(g, v)]; // entries >= M stay zero
+      z0 = fma_(BT.t[0][v], ur, z0);
+      z1 = fma_(BT.t[1][v], ur, z1);
+    }
+    if (more)
+      fetch_AB(i + 1);
+    z0 = sum_groups(z0), z1 = sum_groups(z1);
+    if (g == 0)
+      s_z[j] = z0, s_z[16 + j] = z1;
+    __syncthreads();
+    // y_c = g_c + W_c z ; x_c = z + c_c - delta_c o y_c
+    const v4 zr[2] = {by_row<S>(s_z, 0, g), by_row<S>(s_z, 1, g)};
+    S y0 = S(0), y1 = S(0);
+    mat_t_vec<S>(Wc, zr, y0, y1);
+    y0 = gc0 + sum_groups(y0), y1 = gc1 + sum_groups(y1);
+    const S xn0 = z0 + (cc0 - dc0 * y0), xn1 = z1 + (cc1 - dc1 * y1);
+    if (more)
+      fetch_W(i + 1);
+    S *si = ps + (long)i * VSTG;
+    if (g == 0) {
+      if (acol < M)
+        si[2 * N + acol] = ub;
+      si[VSTG + j] = xn0, si[VSTG + 16 + j] = xn1;
+      si[VSTG + N + j] = y0, si[VSTG + N + 16 + j] = y1;
+      s_x[j] = xn0, s_x[16 + j] = xn1;
+    }
+    __syncthreads();
+  }
+}
+
+} // namespace mt16
+} // namespace sipamd

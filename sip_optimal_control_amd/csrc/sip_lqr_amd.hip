@@ -15,6 +15,7 @@
 #include <memory>
 
 #include "chain_mf32.hpp"
+#include "mt16_launch.hpp"
 #include "generic_plan.hpp"
 #include "qw16_launch.hpp"
 #include "stream_fill.hpp"
@@ -85,12 +86,16 @@ using sipamd::KernelEntry;
 
 const KernelEntry kKernels[] = {
 #if defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_C4) // tools/ab_build.sh: one kernel alone, for A/B timing
-    MF32(8),
+    MT16_ENTRY(SIP_LQR_F32, float, "f32", 8), MF32(8),
 #elif defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_DIRECT)
     QW16_STAGED(14, 8), QW16_STAGED(15, 4), QW16_STAGED(13, 5), QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(12, 6),
 #elif defined(SIP_QW16_QUICK)
     QW16_STAGED(12, 4),
 #else
+    // n = 32 on 16 x 16 matrix-core tiles (chain_mt16.hpp), fp32 and fp64; the 32x32x2 kernel of round 1
+    // (chain_mf32.hpp) stays selectable by SIP_LQR_VARIANT=mf32 for A/B timing
+    MT16_ENTRY(SIP_LQR_F32, float, "f32", 8), MT16_ENTRY(SIP_LQR_F32, float, "f32", 4),
+    MT16_ENTRY(SIP_LQR_F64, double, "f64", 8), MT16_ENTRY(SIP_LQR_F64, double, "f64", 4),
     MF32(8), QW16_STAGED_MR(12, 4), QW16_STAGED_MR(4, 2), QW16_DIRECT(12, 4),
     QW16_DIRECT(4, 2),  QW16_STAGED(1, 1), QW16_STAGED(2, 1),
     QW16_STAGED(3, 2),  QW16_STAGED_MR(8, 3),
@@ -418,7 +423,7 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
   p->ws_slot = k ? k->ws_slot : 0;
   p->launch_fs = k ? k->launch_fs : nullptr;
   p->launch_mrhs = (k != nullptr && !p->padded) ? k->launch_mrhs : nullptr;
-  p->solve_only = k != nullptr && k->dtype == SIP_LQR_F64;
+  p->solve_only = k != nullptr && k->dtype == SIP_LQR_F64 && k->n <= 16; // qw16 only (mt16 re-runs the sweep)
   const char *split = std::getenv("SIP_LQR_SPLIT");
   p->split_on_fused = p->launch_fs != nullptr && !(split && std::strcmp(split, "general") == 0);
   init_generic(p);

@@ -59,7 +59,7 @@ def test_plan_sizes_and_errors(lib):
     assert b"qw16" in lib.sip_lqr_kernel_name(h)
     lib.sip_lqr_plan_destroy(h)
     # shapes without a dedicated kernel go to the general GPU engine (never to the host)
-    assert lib.sip_lqr_plan_create(0, 8, 5, 19, 3, 0, ctypes.byref(h)) == 0
+    assert lib.sip_lqr_plan_create(0, 8, 5, 35, 3, 0, ctypes.byref(h)) == 0
     assert b"tree_generic" in lib.sip_lqr_kernel_name(h)
     lib.sip_lqr_plan_destroy(h)
     assert lib.sip_lqr_plan_create(1, 8, 100, 32, 8, 0, ctypes.byref(h)) == 0   # C4 shape, fp32
@@ -98,7 +98,14 @@ def test_kernel_selection_and_embedding(lib, monkeypatch):
             kernel, _ = name(n, m)
             assert f"qw16<{n},{m}," in kernel and "embedding" not in kernel, (n, m, kernel)
             assert ("staged" in kernel) == (n <= 15), (n, m, kernel)
-    assert "tree_generic" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
+    # 16 < n <= 32, m <= 8: the n = 32 matrix-core kernel (chain_mt16.hpp), exact at (32, 4) and (32, 8), an
+    # embedding below; beyond that the general engine
+    assert name(32, 8)[0] == "chain_factor_solve_mt16<32,8,mfma16x16x4>/f64"
+    assert name(32, 4)[0] == "chain_factor_solve_mt16<32,4,mfma16x16x4>/f64"
+    assert name(17, 4)[0] == "chain_factor_solve_mt16<32,4,mfma16x16x4>/f64 embedding (17,4)"
+    assert name(31, 5)[0] == "chain_factor_solve_mt16<32,8,mfma16x16x4>/f64 embedding (31,5)"
+    assert "tree_generic" in name(33, 4)[0] and "tree_generic" in name(12, 9)[0]
+    assert name(32, 8, dtype=1)[0] == "chain_factor_solve_mt16<32,8,mfma16x16x4>/f32"
     # without the extra slices (diagnostic builds; SIP_LQR_EXTRA=0): embedding in the next larger kernel
     monkeypatch.setenv("SIP_LQR_EXTRA", "0")
     assert name(10, 3)[0] == "chain_factor_solve_qw16<12,3,staged>/f64 embedding (10,3)"
@@ -107,7 +114,7 @@ def test_kernel_selection_and_embedding(lib, monkeypatch):
     assert name(15, 7)[0].startswith("chain_factor_solve_qw16<15,8,staged>")
     assert name(15, 3)[0].startswith("chain_factor_solve_qw16<15,4,staged>")
     assert "qw16<16,4,direct>" in name(16, 4)[0]  # distributed-vector mode
-    assert "tree_generic" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
+    assert "mt16" in name(17, 4)[0] and "tree_generic" in name(12, 9)[0]
     assert "tree_generic" in name(10, 3, dtype=1)[0]  # fp32: only the n = 32 kernel is dedicated
     exact_ws, embedded_ws = name(12, 3)[1], name(10, 3)[1]
     assert embedded_ws > exact_ws  # padded copies of mats / vecs / sol / gains live in the workspace

@@ -32,7 +32,7 @@ def test_hip_gains_are_the_control_law_of_the_dense_kkt_solutions(path):
     mats = torch.from_numpy(d["mats"][:1]).to(dtype).cuda()
     vecs = torch.from_numpy(d["vecs"][:1]).to(dtype).cuda()
     solver = BatchedChainLQR(n, m, T, 1, dtype=dtype)
-    assert ("mf32" in solver.kernel_name) if f32 else ("qw16" in solver.kernel_name)
+    assert ("mt16" in solver.kernel_name) if f32 else ("qw16" in solver.kernel_name)
     _, gains, status = solver.factor_solve(mats, vecs)
     torch.cuda.synchronize()
     assert int(status[0]) == 0

@@ -223,7 +223,7 @@ def test_first_call_of_a_general_engine_plan_can_be_the_captured_one(oracle_lib)
     factor_solve of a plan may run under stream capture; replaying the graph gives the oracle's
     result.  (The code object is loaded beforehand by another plan of the same engine.)"""
     from sip_optimal_control_amd import BatchedChainLQR
-    n, m, T, batch = 19, 3, 9, 7
+    n, m, T, batch = 19, 9, 9, 7   # m > 8: no fused kernel and no embedding
     mats, vecs = _make(n, m, T, batch, seed=91)
     warm = BatchedChainLQR(n, m, T, batch)
     assert "tree_generic" in warm.kernel_name

@@ -1,5 +1,6 @@
-"""Parity of the fp32 / n = 32 matrix-core kernel (chain_factor_solve_mf32, BASELINE C4) beyond the
-KKT residual of tests/test_gpu_general_chain.py:
+"""Parity of the fp32 / n = 32 matrix-core kernels (BASELINE C4) -- chain_factor_solve_mt16 (16 x 16 tiles,
+sweep factorisations; the one plans get) and chain_factor_solve_mf32 (32 x 32 tiles, round 1; kept behind
+SIP_LQR_VARIANT=mf32) -- beyond the KKT residual of tests/test_gpu_general_chain.py:
 
 * FactorStatus (lqr.hpp:68-74) with injected failures, exact against the oracle on the fp32-rounded
   problem, including the precedence at a node (G before delta before F: lqr.cpp:696-701, 722-727)
@@ -39,14 +40,22 @@ def _make(batch, seed, T_=T):
                                       dtype=torch.float32, cross_term=0.01)
 
 
-def _solver(batch, T_=T):
+@pytest.fixture(params=["mt16", "mf32"])
+def variant(request, monkeypatch):
+    """mt16: what a plan gets by default; mf32: the round-1 kernel, selected by name."""
+    if request.param != "mt16":
+        monkeypatch.setenv("SIP_LQR_VARIANT", request.param)
+    return request.param
+
+
+def _solver(batch, T_=T, variant="mt16"):
     from sip_optimal_control_amd import BatchedChainLQR
     s = BatchedChainLQR(N, M, T_, batch, dtype=torch.float32)
-    assert "mf32" in s.kernel_name
+    assert variant in s.kernel_name, s.kernel_name
     return s
 
 
-def test_injected_failures_report_the_reference_status(oracle_lib):
+def test_injected_failures_report_the_reference_status(oracle_lib, variant):
     from sip_optimal_control_amd import ChainShape
     T_ = 12
     shape = ChainShape(N, M, T_)
@@ -69,7 +78,7 @@ def test_injected_failures_report_the_reference_status(oracle_lib):
     mats[7, delta(5, 0)] = 0.0; mats[7, Q(5)] = -1e6 * eye_n;  expected[7] = 1  # same node: delta before F
     mats[8, delta(9, 2)] = 0.0; mats[8, R(2)] = -1e4 * eye_m;        expected[8] = 1  # node 9 comes first in postorder
     mats[9, R(8)] = -1e4 * eye_m; mats[9, delta(3, 1)] = 0.0;        expected[9] = 3  # edge 8 comes first
-    solver = _solver(batch, T_)
+    solver = _solver(batch, T_, variant)
     _, _, status = solver.factor_solve(mats, vecs)
     torch.cuda.synchronize()
     _, _, ref_status = oracle_lib.chain_batch(N, M, T_, mats.double().cpu().numpy(), vecs.double().cpu().numpy())
@@ -81,42 +90,42 @@ def test_injected_failures_report_the_reference_status(oracle_lib):
     np.testing.assert_array_equal(st2.cpu().numpy(), ref_status)
 
 
-def test_solution_and_gains_match_the_oracle_on_the_rounded_problem(oracle_lib):
+def test_solution_and_gains_match_the_oracle_on_the_rounded_problem(oracle_lib, variant):
     batch = 6
     mats, vecs = _make(batch, seed=4242)
-    solver = _solver(batch)
+    solver = _solver(batch, variant=variant)
     sol, gains, status = solver.factor_solve(mats, vecs)
     torch.cuda.synchronize()
     ref_sol, ref_gains, ref_status = oracle_lib.chain_batch(N, M, T, mats.double().cpu().numpy(),
                                                             vecs.double().cpu().numpy())
     assert (ref_status == 0).all() and (status.cpu().numpy() == 0).all()
     es, eg = _rel(sol.double().cpu().numpy(), ref_sol), _rel(gains.double().cpu().numpy(), ref_gains)
-    print(f"mf32 vs oracle (fp32-rounded problem): sol {es:.2e}, gains {eg:.2e}")
+    print(f"{variant} vs oracle (fp32-rounded problem): sol {es:.2e}, gains {eg:.2e}")
     assert es < TOL and eg < TOL
 
 
-def test_golden_c4():
+def test_golden_c4(variant):
     d = np.load(os.path.join(GOLD, "chain_c4_n32_m8_T100.npz"))
     assert (int(d["n"]), int(d["m"]), int(d["T"])) == (N, M, T)
     batch = d["mats"].shape[0]
-    solver = _solver(batch)
+    solver = _solver(batch, variant=variant)
     sol, gains, status = solver.factor_solve(torch.from_numpy(d["mats"]).float().cuda(),
                                              torch.from_numpy(d["vecs"]).float().cuda())
     torch.cuda.synchronize()
     assert (status.cpu().numpy() == 0).all()
     es, eg = _rel(sol.double().cpu().numpy(), d["sol"]), _rel(gains.double().cpu().numpy(), d["gains"])
-    print(f"mf32 vs golden C4 (fp64 dense KKT of the unrounded problem): sol {es:.2e}, gains {eg:.2e}")
+    print(f"{variant} vs golden C4 (fp64 dense KKT of the unrounded problem): sol {es:.2e}, gains {eg:.2e}")
     assert es < TOL and eg < TOL
 
 
-def test_full_c4_batch_properties():
+def test_full_c4_batch_properties(variant):
     """batch 4096 (BASELINE C4): every status SUCCESS; the solve is linear in (q, r, c) (sol(a) +
     sol(b) - sol(0) = sol(a + b) up to fp32 rounding); the same launch twice gives the same bits;
     sampled KKT residuals (evaluated in fp64 on the rounded problem) < 2e-4 of the rhs norm."""
     batch = 4096
     mats, va = _make(batch, seed=9)
     _, vb = _make(batch, seed=10)
-    solver = _solver(batch)
+    solver = _solver(batch, variant=variant)
     sa, ga, st = solver.factor_solve(mats, va)
     sa, ga = sa.clone(), ga.clone()
     assert bool((st == 0).all())
@@ -128,7 +137,7 @@ def test_full_c4_batch_properties():
     torch.cuda.synchronize()
     scale = sab.abs().amax(dim=1, keepdim=True)
     lin = float(((sa + sb - s0 - sab).abs() / scale).max())
-    print("mf32 full C4: linearity defect", lin)
+    print(variant, "full C4: linearity defect", lin)
     assert lin < TOL
     par, ch = list(range(T)), list(range(1, T + 1))
     worst = 0.0
@@ -139,5 +148,5 @@ def test_full_c4_batch_properties():
         res = dense_kkt.residual_norm(par, ch, [N] * (T + 1), [M] * T, blocks, x, u, y)
         rhs = np.sqrt(sum(float(v @ v) for k in ("q", "r", "c") for v in blocks[k]))
         worst = max(worst, res / rhs)
-    print("mf32 full C4: worst sampled relative KKT residual", worst)
+    print(variant, "full C4: worst sampled relative KKT residual", worst)
     assert worst < 2e-4
