@@ -16,6 +16,9 @@ hipError_t launch_mt16(long batch, int T, const void *mats, const void *vecs, vo
   return hipGetLastError();
 }
 
+static_assert(mt16::Layout<float, 8>::WSN == kMt16SpillPerNode && mt16::Layout<double, 4>::WSN == kMt16SpillPerNode,
+              "the dispatch table sizes the workspace by kMt16SpillPerNode");
+
 #define SIP_MT16_INSTANTIATE(S, M)                                                                           \
   template hipError_t launch_mt16<S, M>(long, int, const void *, const void *, void *, void *, int32_t *,    \
                                         void *, hipStream_t, int, void *);

@@ -40,6 +40,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Diagnostic build (tools/dev/mt16_stamps.hip): cycles per segment of the backward loop, per wavefront.
+#ifdef SIP_MT16_STAMPS
+#define SIP_MT16_STAMP_ARG , unsigned long long *__restrict__ stamps
+#define SIP_MT16_STAMP(k)                                                                                     \
+  do {                                                                                                       \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                            \
+    seg_[k] += now_ - last_;                                                                                 \
+    last_ = now_;                                                                                            \
+  } while (0)
+#else
+#define SIP_MT16_STAMP_ARG
+#define SIP_MT16_STAMP(k)
+#endif
+
 namespace sipamd {
 namespace mt16 {
 
@@ -54,8 +68,7 @@ template <> struct Tr<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ float rcp(const float x) {
-    const float r = __builtin_amdgcn_rcpf(x);
-    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r); // one Newton step: < 1 ulp
+    return __builtin_amdgcn_rcpf(x); // 1 ulp; the pivots' reciprocals enter P^-1 = M^T D^-1 M linearly
   }
   static __device__ __forceinline__ float uniform(const float x, const int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
@@ -86,6 +99,12 @@ template <> struct Tr<double> {
 // typed fused multiply-add (__builtin_fma on floats would go through double)
 __device__ __forceinline__ float fma_(const float a, const float b, const float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(const double a, const double b, const double c) { return __builtin_fma(a, b, c); }
+
+// The workgroup is ONE wavefront: the LDS instructions of a wavefront execute in order, so a write by some lanes
+// is visible to a later read by others without a barrier.  __syncthreads() would also drain vmcnt -- every
+// outstanding load, spill store and gains store -- six times per stage; this only keeps the compiler from moving
+// memory operations across the point (no instruction is emitted).
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_wave_barrier(); }
 
 template <typename S> struct Mat32 { // 32 x 32: t[I][J]
   typename Tr<S>::v4 t[2][2];
@@ -126,12 +145,31 @@ template <typename S> __device__ __forceinline__ int ctrl_of_col(const int j) {
   return Tr<S>::ROWS_CONTIGUOUS ? (j >> 2) + 4 * (j & 3) : j;
 }
 
-// sum over the four lane groups (lanes j, j + 16, j + 32, j + 48): every lane gets the total
-template <typename S> __device__ __forceinline__ S sum_groups(S x) {
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
-  return x;
+// sum over the four lane groups (lanes j, j + 16, j + 32, j + 48): every lane gets the total.  On the vector
+// pipe: v_permlane32_swap / v_permlane16_swap (gfx950) exchange the halves / the odd and even 16-lane rows of two
+// registers, so x + swap(x) is the sum with the partner row -- no LDS round trip (ds_bpermute) in the dependent
+// chains of the vector work.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sum_groups(const float x) {
+  const unsigned b = __float_as_uint(x);
+  const u32x2 h = __builtin_amdgcn_permlane32_swap(b, b, false, false); // {[lo, lo], [hi, hi]}
+  const float s = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+  const unsigned c = __float_as_uint(s);
+  const u32x2 q = __builtin_amdgcn_permlane16_swap(c, c, false, false); // rows {[0, 0, 2, 2], [1, 1, 3, 3]}
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
+__device__ __forceinline__ double swap_sum(const double x, const bool rows16) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+  const u32x2 a = rows16 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false)
+                         : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const u32x2 b = rows16 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false)
+                         : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double u = __longlong_as_double((long long)(((unsigned long long)b[0] << 32) | a[0]));
+  const double w = __longlong_as_double((long long)(((unsigned long long)b[1] << 32) | a[1]));
+  return u + w;
+}
+__device__ __forceinline__ double sum_groups(const double x) { return swap_sum(swap_sum(x, false), true); }
 
 // vec[16 I + row(g, v)], v = 0..3 (LDS array indexed by row)
 template <typename S>
@@ -161,7 +199,7 @@ __device__ __forceinline__ void mat_t_vec(const Mat32<S> &Mt, const typename Tr<
 // row (all of them for VP = 4).  Returns true iff a pivot was <= 0.  On return the swept rows and
 // columns hold -A^-1 restricted to them (all of -A^-1 for VP = 4).
 template <typename S, int TILES, int VP>
-__device__ __forceinline__ bool sweep(typename Tr<S>::v4 (&T)[TILES][TILES], const LaneT<S> &L) {
+__device__ __forceinline__ bool sweep(typename Tr<S>::v4 (&T)[TILES][TILES], const LaneT<S> &L, S *sp) {
   using TR = Tr<S>;
   using v4 = typename TR::v4;
   bool fail = false;
@@ -169,13 +207,24 @@ __device__ __forceinline__ bool sweep(typename Tr<S>::v4 (&T)[TILES][TILES], con
   for (int I = 0; I < TILES; ++I) {
 #pragma unroll
     for (int v = 0; v < VP; ++v) {
-      // P[a][b] = A[p_a][p_b], p_g = 16 I + row(g, v): register v of lane (j = row(b, v), g = a)
+      // P[a][b] = A[p_a][p_b], p_g = 16 I + row(g, v): register v of lane (j = row(b, v), g = a).  Through
+      // LDS rather than v_readlane: the 16 lanes that hold P write it compactly, every lane reads it back as
+      // four broadcast 16-byte reads -- no vector-pipe time (a v_readlane costs 7 to 26 cycles of it, and the
+      // f32 matrix instructions share that pipe), no SGPR operands in the arithmetic below.
       S P[4][4];
+      {
+        const int b_of_j = TR::ROWS_CONTIGUOUS ? (L.j >> 2) : (L.j & 3); // j = row(b, v') for this b
+        const int v_of_j = TR::ROWS_CONTIGUOUS ? (L.j & 3) : (L.j >> 2); //   and this v'
+        if (v_of_j == v)
+          sp[4 * L.g + b_of_j] = T[I][I][v];
+        lds_order();
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b <= a; ++b)
-          P[a][b] = TR::uniform(T[I][I][v], 16 * a + TR::row(b, v));
+          for (int b = 0; b <= a; ++b)
+            P[a][b] = sp[4 * a + b];
+        lds_order();
+      }
       // LDL^T of P: the pivots d_k are those of an unblocked Cholesky (squared)
       const S d0 = P[0][0], i0 = TR::rcp(d0);
       const S l10 = P[1][0] * i0, l20 = P[2][0] * i0, l30 = P[3][0] * i0;
@@ -188,8 +237,13 @@ __device__ __forceinline__ bool sweep(typename Tr<S>::v4 (&T)[TILES][TILES], con
       const S d3 = fma_(-l32, t32, fma_(-l31, t31, fma_(-l30, P[3][0], P[3][3])));
       const S i3 = TR::rcp(d3);
       fail |= !(d0 > S(0)) | !(d1 > S(0)) | !(d2 > S(0)) | !(d3 > S(0));
-      // M = L^-1 (unit lower), P^-1 = M^T D^-1 M.  Lane group g only needs column g of P^-1 (it is the
-      // k index of the mix's A operand): y = M^T D^-1 M e_g with the one-hot e_g of the lane group.
+      // With M = L^-1 (unit lower) and X = C^T - [I on the pivot columns] (register v of tile row I as it stands,
+      // minus one on the diagonal lanes) the whole step is  A <- A - Y^T D^-1 Y,  Y = M X :
+      //   mix    Y_J = M X_J : the A operand carries M[kk][kq] on lane (i = row(kk, 0), kq = g), so that the result
+      //          lands in register 0 of lane group kk -- which is both the B operand layout of Y and the A operand
+      //          layout of Y^T;
+      //   update A[It][Jt] += (-Y_It)^T-as-A-operand * (d_g^-1 Y_Jt)-as-B-operand.
+      // Column g of M for this lane group, by the one-hot of the group (no selects, no P^-1):
       const S m10 = -l10, m21 = -l21, m32 = -l32;
       const S m20 = fma_(l21, l10, -l20);
       const S m31 = fma_(l32, l21, -l31);
@@ -197,22 +251,17 @@ __device__ __forceinline__ bool sweep(typename Tr<S>::v4 (&T)[TILES][TILES], con
       const S t1 = fma_(m10, L.eg[0], L.eg[1]);
       const S t2 = fma_(m20, L.eg[0], fma_(m21, L.eg[1], L.eg[2]));
       const S t3 = fma_(m30, L.eg[0], fma_(m31, L.eg[1], fma_(m32, L.eg[2], L.eg[3])));
-      const S w0 = i0 * L.eg[0], w1 = i1 * t1, w2 = i2 * t2, w3 = i3 * t3;
-      const S y2 = fma_(m32, w3, w2);
-      const S y1 = fma_(m31, w3, fma_(m21, w2, w1));
-      const S y0 = fma_(m30, w3, fma_(m20, w2, fma_(m10, w1, w0)));
-      // A operand of the mix: P^-1[kk][kq] on lane (i = row(kk, 0), kq = g); its result lands in register 0
-      // of lane group kk, where the update wants its B operand
-      const S amix = fma_(L.ej[0], y0, fma_(L.ej[1], y1, fma_(L.ej[2], y2, L.ej[3] * w3)));
+      const S amix = fma_(L.ej[0], L.eg[0], fma_(L.ej[1], t1, fma_(L.ej[2], t2, L.ej[3] * t3)));
+      const S ig = fma_(i0, L.eg[0], fma_(i1, L.eg[1], fma_(i2, L.eg[2], i3 * L.eg[3]))); // 1 / d_g
       const bool diag = L.j == TR::row(L.g, v); // this lane's register v of tile (I, I) is a diagonal element
       const S one_d = diag ? S(1) : S(0);
       S bop[TILES], aop[TILES];
 #pragma unroll
       for (int Jt = 0; Jt < TILES; ++Jt) {
         const S src = T[I][Jt][v] - (Jt == I ? one_d : S(0));
-        aop[Jt] = -src; // tile (I, Jt) register v is also -C^T of output tile row Jt
         const v4 mixed = TR::mfma(amix, src, zero4<S>());
-        bop[Jt] = mixed[0];
+        aop[Jt] = -mixed[0];
+        bop[Jt] = mixed[0] * ig;
       }
 #pragma unroll
       for (int It = 0; It < TILES; ++It)
@@ -229,7 +278,8 @@ template <typename S, int M> struct Layout {
   static constexpr int NODE = N * N + N;                 // Q | delta
   static constexpr int EDGE = N * N + 2 * N * M + M * M; // A | B | M | R
   static constexpr int VNODE = 2 * N, VEDGE = M, GAIN = M * N + M;
-  static constexpr int WSN = N * N + N; // W (tile dump) | g
+  // spill per node: tiles (0, 0), (1, 0), (1, 1) of the symmetric W as they sit in the registers | g
+  static constexpr int WTILES = 3, WSN = WTILES * 256 + N;
   static constexpr int VM = (M + 3) / 4; // registers of a lane that hold controls
   // 16-byte loads of four consecutive rows need every block 16-byte aligned
   static constexpr bool VEC_LOADS = Tr<S>::ROWS_CONTIGUOUS && (EDGE % 4 == 0);
@@ -256,11 +306,24 @@ __device__ __forceinline__ Mat32<S> load32(const S *m, const LaneT<S> &L) {
   return r;
 }
 
+// Waves per SIMD the register allocator is held to (BASELINE's batch of 4096 = 4 wavefronts per SIMD: with 3
+// resident the fourth runs alone behind them): 4 in fp32 (128 VGPRs; the few loop-invariant lane constants that
+// do not fit are re-read from scratch), 2 in fp64.
+#ifndef SIP_MT16_WAVES_F32
+#define SIP_MT16_WAVES_F32 4
+#endif
+template <typename S> struct Waves { static constexpr int value = sizeof(S) == 4 ? SIP_MT16_WAVES_F32 : 2; };
+
 template <typename S, int M>
-__global__ __launch_bounds__(64) void chain_factor_solve_mt16(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Waves<S>::value, Waves<S>::value)))
+void chain_factor_solve_mt16(
     const S *__restrict__ mats, const S *__restrict__ vecs, S *__restrict__ sol, S *__restrict__ gains,
-    S *__restrict__ wsp, int *__restrict__ status, const long batch, const int T) {
+    S *__restrict__ wsp, int *__restrict__ status, const long batch, const int T SIP_MT16_STAMP_ARG) {
   static_assert(M >= 1 && M <= 8, "controls live in registers 0 and 1 of the four lane groups");
+#ifdef SIP_MT16_STAMPS
+  unsigned long long seg_[16] = {0}, last_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long start_ = last_;
+#endif
   using TR = Tr<S>;
   using v4 = typename TR::v4;
   using LY = Layout<S, M>;
@@ -287,6 +350,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
   __shared__ S s_v[N], s_t[N], s_g[N], s_sd[N], s_sdi[N], s_x[N], s_z[N], s_gs[16], s_h[8], s_u[8];
   constexpr int LDM = TR::ROWS_CONTIGUOUS ? 36 : 33; // column stride of the mirror image (bank spread; 16-byte columns)
   __shared__ __attribute__((aligned(16))) S s_m[N * LDM];
+  __shared__ __attribute__((aligned(16))) S s_p[16]; // pivot block of the sweep's current step
+
 
   if (L.lane < 8)
     s_h[L.lane] = S(0), s_u[L.lane] = S(0); // the entries of no control are read as zeros
@@ -295,10 +360,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
 
   // ---- node tail: F = I + D^1/2 V D^1/2, its sweep, W (lqr.cpp:487-529, 722-727), plus the vector
   // term t = c - delta o v for the parent step.
-  auto finish_node = [&](const int i) {
-    const S *nm = pm + (long)i * STG;
-    const S *nv = pv + (long)i * VSTG;
-    const S dl0 = nm[N * N + j], dl1 = nm[N * N + 16 + j];
+  auto finish_node = [&](const int i, const S dl0, const S dl1, const S c0, const S c1) {
     if (stat == 0 && __any(!(dl0 > S(0)) || !(dl1 > S(0))))
       stat = 1; // INVALID_DELTA
     const S sd0 = TR::sqrt(dl0), sd1 = TR::sqrt(dl1);
@@ -306,9 +368,10 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
     if (g == 0) {
       s_sd[j] = sd0, s_sd[16 + j] = sd1;
       s_sdi[j] = sdi0, s_sdi[16 + j] = sdi1;
-      s_t[j] = nv[N + j] - dl0 * s_v[j]; // c - delta o v   (lqr.cpp:778-779, negated)
-      s_t[16 + j] = nv[N + 16 + j] - dl1 * s_v[16 + j];
+      s_t[j] = c0 - dl0 * s_v[j]; // c - delta o v   (lqr.cpp:778-779, negated)
+      s_t[16 + j] = c1 - dl1 * s_v[16 + j];
     }
+    SIP_MT16_STAMP(7);
     // Only the lower triangle of V counts (Eigen::LLT reads nothing else, lqr.cpp:505): mirror it through
     // LDS.  V = Q + A^T F + K^T H is symmetric only up to rounding, the sweep reads rows as columns, and the
     // recursion does not damp an antisymmetric part (the feedback term K^T H is symmetric by construction):
@@ -326,7 +389,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
             col[TR::row(g, v)] = V.t[I][J][v];
         }
       }
-    __syncthreads();
+    lds_order();
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -350,7 +413,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
             V.t[I][J][v] = fma_(V.t[I][J][v] * sr[I][v], J == 0 ? sd0 : sd1, dg ? S(1) : S(0));
           }
     }
-    const bool ffail = sweep<S, 2, 4>(V.t, L); // V now holds -F^-1
+    SIP_MT16_STAMP(8);
+    const bool ffail = sweep<S, 2, 4>(V.t, L, s_p); // V now holds -F^-1
+    SIP_MT16_STAMP(9);
     if (stat == 0 && ffail)
       stat = 2; // F_FACTORIZATION_FAILURE
     // W = D^-1/2 (I - F^-1) D^-1/2
@@ -366,14 +431,13 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
             W.t[I][J][v] = (V.t[I][J][v] + (dg ? S(1) : S(0))) * (ir[I][v] * (J == 0 ? sdi0 : sdi1));
           }
     }
-    // spill W (tile dump) for the rollout
+    // spill W for the rollout: W is symmetric, tile (0, 1) is read back out of the dump of tile (1, 0)
     v4 *wd = (v4 *)(pw + (long)i * LY::WSN);
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-      for (int J = 0; J < 2; ++J)
-        wd[(2 * I + J) * 64 + L.lane] = W.t[I][J];
-    __syncthreads();
+    wd[0 * 64 + L.lane] = W.t[0][0];
+    wd[1 * 64 + L.lane] = W.t[1][0];
+    wd[2 * 64 + L.lane] = W.t[1][1];
+    lds_order();
+    SIP_MT16_STAMP(10);
   };
 
   // ---- terminal node -------------------------------------------------------------------------
@@ -382,8 +446,12 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
     s_v[j] = pv[(long)T * VSTG + j]; // v = q
     s_v[16 + j] = pv[(long)T * VSTG + 16 + j];
   }
-  __syncthreads();
-  finish_node(T);
+  {
+    const S *nm = pm + (long)T * STG, *nv = pv + (long)T * VSTG;
+    const S dl0 = nm[N * N + j], dl1 = nm[N * N + 16 + j], c0 = nv[N + j], c1 = nv[N + 16 + j];
+    lds_order();
+    finish_node(T, dl0, dl1, c0, c1);
+  }
 
   // ---- backward recursion --------------------------------------------------------------------
   for (int i = T - 1; i >= 0; --i) {
@@ -392,6 +460,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
     const S *nv = pv + (long)i * VSTG;
     const S *Bm = em + N * N, *Mm = Bm + N * M, *Rm = Mm + N * M;
     const Mat32<S> A = load32<S, VEC>(em, L);
+    // the node's and the edge's vectors: requested here, used at the bottom of the stage
+    const S dl0 = nm[N * N + j], dl1 = nm[N * N + 16 + j], c0 = nv[N + j], c1 = nv[N + 16 + j];
+    const S q0 = nv[j], q1 = nv[16 + j], rv = nv[LY::VNODE + (acol < M ? acol : 0)];
     // B (32 x M, ld 32): control acol on tile column j; columns of no control are zero
     Pair<S> B;
 #pragma unroll
@@ -434,10 +505,11 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
       const S g0 = s_v[j] + sum_groups(w0), g1 = s_v[16 + j] + sum_groups(w1);
       if (g == 0) {
         s_g[j] = g0, s_g[16 + j] = g1;
-        pw[(long)(i + 1) * LY::WSN + N * N + j] = g0;
-        pw[(long)(i + 1) * LY::WSN + N * N + 16 + j] = g1;
+        pw[(long)(i + 1) * LY::WSN + LY::WTILES * 256 + j] = g0;
+        pw[(long)(i + 1) * LY::WSN + LY::WTILES * 256 + 16 + j] = g1;
       }
     }
+    SIP_MT16_STAMP(0);
     Mat32<S> F;
     Pair<S> Z;
 #pragma unroll
@@ -468,7 +540,8 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
         H.t[0] = TR::mfma(B.t[R][v], F.t[R][0][v], H.t[0]);
         H.t[1] = TR::mfma(B.t[R][v], F.t[R][1][v], H.t[1]);
       }
-    __syncthreads(); // s_g
+    SIP_MT16_STAMP(1);
+    lds_order(); // s_g
     const v4 gr[2] = {by_row<S>(s_g, 0, g), by_row<S>(s_g, 1, g)};
     // h = r + B^T g  (lqr.cpp:783-784): control acol on the lanes of tile column j
     {
@@ -480,8 +553,9 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
           pb = fma_(B.t[I][v], gr[I][v], pb);
       pb = sum_groups(pb);
       if (g == 0 && acol < M)
-        s_h[acol] = nv[LY::VNODE + acol] + pb;
+        s_h[acol] = rv + pb;
     }
+    SIP_MT16_STAMP(2);
     // LLT of G (lqr.cpp:696-701) as a sweep: G <- -G^-1 on the control rows / columns.  The sweep's modified
     // operands work against an identity on the pivot block, which costs accuracy when the pivots are far from
     // 1 (G ~ R is not scaled like F = I + ...): sweep the unit-diagonal S G S, S = diag(G)^-1/2, and scale back.
@@ -493,19 +567,20 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
       const S sc = TR::rsqrt(sum_groups(dsel)); // of tile column j; NaN for a diagonal <= 0: the sweep then fails
       if (g == 0)
         s_gs[j] = sc;
-      __syncthreads();
+      lds_order();
       const v4 sr = by_row<S>(s_gs, 0, g);
       v4 Gt[1][1];
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         Gt[0][0][v] = G[v] * (sr[v] * sc);
-      const bool gfail = sweep<S, 1, VM>(Gt, L);
+      const bool gfail = sweep<S, 1, VM>(Gt, L, s_p);
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         G[v] = Gt[0][0][v] * (sr[v] * sc);
       if (stat == 0 && gfail)
         stat = 3; // G_FACTORIZATION_FAILURE
     }
+    SIP_MT16_STAMP(3);
     // K = -G^-1 H   (lqr.cpp:707-713); -G^-1 symmetric
     Pair<S> K;
     K.t[0] = zero4<S>(), K.t[1] = zero4<S>();
@@ -514,7 +589,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
       K.t[0] = TR::mfma(G[v], H.t[0][v], K.t[0]);
       K.t[1] = TR::mfma(G[v], H.t[1][v], K.t[1]);
     }
-    __syncthreads(); // s_h
+    lds_order(); // s_h
     S hr[VM];
 #pragma unroll
     for (int v = 0; v < VM; ++v)
@@ -546,24 +621,39 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
         p0 = fma_(K.t[0][v], hr[v], p0);
         p1 = fma_(K.t[1][v], hr[v], p1);
       }
-      const S vn0 = nv[j] + sum_groups(p0), vn1 = nv[16 + j] + sum_groups(p1);
-      __syncthreads(); // everyone is done with s_v / s_t / s_g of the child
+      const S vn0 = q0 + sum_groups(p0), vn1 = q1 + sum_groups(p1);
+      lds_order(); // everyone is done with s_v / s_t / s_g of the child
       if (g == 0)
         s_v[j] = vn0, s_v[16 + j] = vn1;
     }
-    // V = Q + A^T F + K^T H   (lqr.cpp:715-719)
-    V = load32<S, VEC>(nm, L);
-    mul_tt<S>(A, F, V);
+    SIP_MT16_STAMP(4);
+    // V = Q + A^T F + K^T H   (lqr.cpp:715-719): tiles (0, 0), (1, 0), (1, 1) only -- the node tail keeps the lower
+    // triangle and mirrors it, so tile (0, 1) is never read (10 MFMAs and a 16-byte load less per stage)
+    {
+      const Mat32<S> Qm = load32<S, VEC>(nm, L); // (its tile (0, 1) is dead code)
+      V.t[0][0] = Qm.t[0][0], V.t[1][0] = Qm.t[1][0], V.t[1][1] = Qm.t[1][1];
+    }
 #pragma unroll
-    for (int v = 0; v < VM; ++v)
+    for (int R = 0; R < 2; ++R)
 #pragma unroll
-      for (int I = 0; I < 2; ++I)
+      for (int v = 0; v < 4; ++v) {
+        V.t[0][0] = TR::mfma(A.t[R][0][v], F.t[R][0][v], V.t[0][0]);
+        V.t[1][0] = TR::mfma(A.t[R][1][v], F.t[R][0][v], V.t[1][0]);
+        V.t[1][1] = TR::mfma(A.t[R][1][v], F.t[R][1][v], V.t[1][1]);
+      }
 #pragma unroll
-        for (int J = 0; J < 2; ++J)
-          V.t[I][J] = TR::mfma(K.t[I][v], H.t[J][v], V.t[I][J]);
-    __syncthreads();
-    finish_node(i);
+    for (int v = 0; v < VM; ++v) {
+      V.t[0][0] = TR::mfma(K.t[0][v], H.t[0][v], V.t[0][0]);
+      V.t[1][0] = TR::mfma(K.t[1][v], H.t[0][v], V.t[1][0]);
+      V.t[1][1] = TR::mfma(K.t[1][v], H.t[1][v], V.t[1][1]);
+    }
+    lds_order();
+    SIP_MT16_STAMP(5);
+    finish_node(i, dl0, dl1, c0, c1);
   }
+#ifdef SIP_MT16_STAMPS
+  const unsigned long long back_end_ = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- root: g_0 = v_0 + W_0 t_0 ; x_0 = c_0 - delta_0 o g_0, y_0 = g_0 -----------------------
   {
@@ -580,7 +670,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
   }
   if (L.lane == 0)
     status[p] = stat;
-  __syncthreads();
+  lds_order();
 
   // ---- forward rollout (lqr.cpp:821-870) -----------------------------------------------------
   // The products sum over the rows of the tile, so the operands are loaded transposed (K^T, A^T, B^T:
@@ -624,12 +714,16 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
     const S *nv1 = pv + (long)(i + 1) * VSTG;
     const S *wn = pw + (long)(i + 1) * LY::WSN;
     const v4 *wd = (const v4 *)wn;
+    Wc.t[0][0] = wd[0 * 64 + L.lane], Wc.t[1][0] = wd[1 * 64 + L.lane], Wc.t[1][1] = wd[2 * 64 + L.lane];
+    // tile (0, 1) = tile (1, 0) transposed: element (row(g, v), 16 + j) is W(16 + j, row(g, v)), which the dump of
+    // tile (1, 0) holds in register v' of lane (row(g, v), g') with row(g', v') = j
+    {
+      const int gq = TR::ROWS_CONTIGUOUS ? (j >> 2) : (j & 3), vq = TR::ROWS_CONTIGUOUS ? (j & 3) : (j >> 2);
 #pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-      for (int J = 0; J < 2; ++J)
-        Wc.t[I][J] = wd[(2 * I + J) * 64 + L.lane];
-    gc0 = wn[N * N + j], gc1 = wn[N * N + 16 + j];
+      for (int v = 0; v < 4; ++v)
+        Wc.t[0][1][v] = wn[(1 * 64 + 16 * gq + TR::row(g, v)) * 4 + vq];
+    }
+    gc0 = wn[LY::WTILES * 256 + j], gc1 = wn[LY::WTILES * 256 + 16 + j];
     cc0 = nv1[N + j], cc1 = nv1[N + 16 + j];
     dc0 = nm1[N * N + j], dc1 = nm1[N * N + 16 + j];
   };
@@ -653,7 +747,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
       fetch_K(i + 1);
     if (g == 0 && acol < M)
       s_u[acol] = ub;
-    __syncthreads();
+    lds_order();
     // z = A x + B u
     S z0 = S(0), z1 = S(0);
     mat_t_vec<S>(AT, xr, z0, z1);
@@ -668,7 +762,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
     z0 = sum_groups(z0), z1 = sum_groups(z1);
     if (g == 0)
       s_z[j] = z0, s_z[16 + j] = z1;
-    __syncthreads();
+    lds_order();
     // y_c = g_c + W_c z ; x_c = z + c_c - delta_c o y_c
     const v4 zr[2] = {by_row<S>(s_z, 0, g), by_row<S>(s_z, 1, g)};
     S y0 = S(0), y1 = S(0);
@@ -685,8 +779,16 @@ __global__ __launch_bounds__(64) void chain_factor_solve_mt16(
       si[VSTG + N + j] = y0, si[VSTG + N + 16 + j] = y1;
       s_x[j] = xn0, s_x[16 + j] = xn1;
     }
-    __syncthreads();
+    lds_order();
   }
+#ifdef SIP_MT16_STAMPS
+  if (stamps != nullptr && L.lane == 0) {
+    unsigned long long *o = stamps + (long)blockIdx.x * 20;
+    o[0] = start_, o[1] = back_end_, o[2] = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < 16; ++k)
+      o[3 + k] = seg_[k];
+  }
+#endif
 }
 
 } // namespace mt16

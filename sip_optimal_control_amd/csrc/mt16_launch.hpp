@@ -13,7 +13,7 @@ template <typename S, int M>
 hipError_t launch_mt16(long batch, int T, const void *mats, const void *vecs, void *sol, void *gains,
                        int32_t *status, void *ws, hipStream_t stream, int mode, void *gfac);
 
-constexpr int kMt16SpillPerNode = 32 * 32 + 32; // Layout::WSN: W (tile dump) | g
+constexpr int kMt16SpillPerNode = 3 * 256 + 32; // Layout::WSN: three tiles of the symmetric W | g
 
 } // namespace sipamd
 
