@@ -306,11 +306,12 @@ __device__ __forceinline__ Mat32<S> load32(const S *m, const LaneT<S> &L) {
   return r;
 }
 
-// Waves per SIMD the register allocator is held to (BASELINE's batch of 4096 = 4 wavefronts per SIMD: with 3
-// resident the fourth runs alone behind them): 4 in fp32 (128 VGPRs; the few loop-invariant lane constants that
-// do not fit are re-read from scratch), 2 in fp64.
+// Waves per SIMD the register allocator is held to.  fp32: 3 (168 VGPRs, no scratch).  BASELINE's batch of 4096 is
+// 4 wavefronts per SIMD, so a fourth runs behind the first three; holding the allocator to 4 (128 VGPRs) keeps all
+// four resident but spills ~30 loop-invariant lane constants and schedules the rest more tightly: measured 2.61 ms
+// against 2.43 ms at 3 (bench.py --workload c4), 10.6 k against 8.1 k cycles of a SIMD per problem-stage.
 #ifndef SIP_MT16_WAVES_F32
-#define SIP_MT16_WAVES_F32 4
+#define SIP_MT16_WAVES_F32 3
 #endif
 template <typename S> struct Waves { static constexpr int value = sizeof(S) == 4 ? SIP_MT16_WAVES_F32 : 2; };
 
