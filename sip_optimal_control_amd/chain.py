@@ -166,6 +166,11 @@ class BatchedChainLQR:
             ctypes.c_void_p(stream.cuda_stream)), "sip_lqr_solve")
         return sol
 
+    def solve_multi_workspace_bytes(self, num_rhs):
+        """Column workspace sip_lqr_solve_multi needs for `num_rhs` columns; 0: the shape has no multi-rhs kernel
+        and the columns are solved one by one."""
+        return int(self._lib.sip_lqr_solve_multi_workspace_bytes(self._plan, int(num_rhs)))
+
     def solve_multi(self, mats, vecs_cols, gains, sol_cols=None, stream=None):
         """LQR::solve() for several right-hand sides against the last factor() (the multi-rhs block of
         solve_stagewise_kkt_matrix, helpers.cpp:521-665): vecs_cols / sol_cols are [num_rhs, batch,

@@ -96,9 +96,9 @@ const KernelEntry kKernels[] = {
     // (chain_mf32.hpp) stays selectable by SIP_LQR_VARIANT=mf32 for A/B timing
     MT16_ENTRY(SIP_LQR_F32, float, "f32", 8), MT16_ENTRY(SIP_LQR_F32, float, "f32", 4),
     MT16_ENTRY(SIP_LQR_F64, double, "f64", 8), MT16_ENTRY(SIP_LQR_F64, double, "f64", 4),
-    MF32(8), QW16_STAGED_MR(12, 4), QW16_STAGED_MR(4, 2), QW16_DIRECT(12, 4),
-    QW16_DIRECT(4, 2),  QW16_STAGED(1, 1), QW16_STAGED(2, 1),
-    QW16_STAGED(3, 2),  QW16_STAGED_MR(8, 3),
+    MF32(8), QW16_STAGED_MR(12, 4), QW16_STAGED_MR(4, 2), QW16_DIRECT_MR(12, 4),
+    QW16_DIRECT_MR(4, 2),  QW16_STAGED_MR(1, 1), QW16_STAGED_MR(2, 1),
+    QW16_STAGED_MR(3, 2),  QW16_STAGED_MR(8, 3),
     // the grid of the reference's benchmarks (lqr_benchmark.cpp:537-545,
     // newton_kkt_benchmark.cpp:264-273: n in {4, 6, 8}, m in {1, 2, 3, 4}; n = 16 has no
     // vector lane left and runs on the general engine) and n = 12 with fewer controls
@@ -107,10 +107,10 @@ const KernelEntry kKernels[] = {
     QW16_STAGED_MR(6, 1),  QW16_STAGED_MR(6, 3),  QW16_STAGED_MR(8, 1),  QW16_STAGED_MR(12, 1),
     QW16_STAGED_MR(12, 3),
     // hosts for the embedding of larger shapes (n <= 15: one lane of the row carries the affine column)
-    QW16_STAGED(8, 8),  QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(14, 8), QW16_STAGED(15, 4),
-    QW16_STAGED(15, 8),
+    QW16_STAGED_MR(8, 8),  QW16_STAGED_MR(12, 8), QW16_STAGED_MR(14, 4), QW16_STAGED_MR(14, 8), QW16_STAGED_MR(15, 4),
+    QW16_STAGED_MR(15, 8),
     // n = 16 (in the reference's benchmark grid): distributed-vector mode, see chain_qw16.hpp
-    QW16_DIRECT_MR(16, 1), QW16_DIRECT_MR(16, 2), QW16_DIRECT_MR(16, 3), QW16_DIRECT_MR(16, 4), QW16_DIRECT(16, 8),
+    QW16_DIRECT_MR(16, 1), QW16_DIRECT_MR(16, 2), QW16_DIRECT_MR(16, 3), QW16_DIRECT_MR(16, 4), QW16_DIRECT_MR(16, 8),
 #endif
 };
 

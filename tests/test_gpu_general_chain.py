@@ -265,12 +265,18 @@ def test_plan_device_is_explicit_and_left_alone(oracle_lib):
 
 
 @pytest.mark.parametrize("n,m,T,batch,cols", [(12, 4, 50, 37, 8), (12, 4, 7, 5, 11), (4, 2, 9, 6, 3), (8, 3, 6, 9, 8),
-                                             (16, 4, 5, 5, 2), (6, 1, 4, 3, 1), (10, 3, 6, 4, 5), (12, 4, 0, 3, 2)])
+                                             (16, 4, 5, 5, 2), (6, 1, 4, 3, 1), (10, 3, 6, 4, 5), (12, 4, 0, 3, 2),
+                                             # round 3: every shape n <= 16, m <= 8 has the multi-rhs kernel
+                                             (5, 3, 8, 6, 8), (13, 5, 6, 5, 9), (15, 8, 5, 4, 3), (9, 6, 7, 5, 8),
+                                             (16, 8, 4, 5, 4), (1, 1, 6, 4, 2), (7, 8, 5, 3, 8), (11, 2, 9, 5, 16),
+                                             # beyond: the n = 32 kernel (and an embedding in it), column by column
+                                             (32, 8, 5, 3, 2), (20, 3, 4, 3, 2)])
 def test_solve_multi_carries_every_right_hand_side(oracle_lib, n, m, T, batch, cols):
     """sip_lqr_solve_multi (the multi-rhs block of solve_stagewise_kkt_matrix, helpers.cpp:521-665):
     factor once, then `cols` right-hand sides in one sweep per 8 columns (chain_mrhs.hpp; more than 8,
-    a staged and a direct factor state, n = 16, and a shape without the kernel -- (10, 3): column by
-    column -- among the cases), each column against the oracle's solve of that right-hand side."""
+    a staged and a direct factor state, n = 16, odd and large shapes among the cases; n > 16 has no such kernel
+    and goes column by column behind the same entry point), each column against the oracle's solve of that
+    right-hand side."""
     from sip_optimal_control_amd import BatchedChainLQR, ChainShape
     shape = ChainShape(n, m, T)
     mats, _ = _make(n, m, T, batch, seed=700 + n)
@@ -280,6 +286,7 @@ def test_solve_multi_carries_every_right_hand_side(oracle_lib, n, m, T, batch, c
     gen = torch.Generator(device="cuda:0").manual_seed(5)
     vecs_cols = torch.randn(cols, batch, shape.vecs_len, dtype=torch.float64, device="cuda:0", generator=gen)
     solver = BatchedChainLQR(n, m, T, batch)
+    assert (solver.solve_multi_workspace_bytes(cols) > 0) == (n <= 16 and m <= 8)   # one sweep per 8 columns
     gains, status = solver.factor(mats)
     sol_cols = solver.solve_multi(mats, vecs_cols, gains)
     torch.cuda.synchronize()
