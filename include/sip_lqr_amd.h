@@ -297,6 +297,15 @@ size_t sip_lqr_tree_fused_scratch_bytes(const sip_lqr_tree_plan *plan);
 int sip_lqr_tree_factor_solve(const sip_lqr_tree_plan *plan, const double *d_input,
                               double *d_work, double *d_output, int32_t *d_status,
                               void *d_scratch, void *stream);
+/* The same fused sweep, leaving in d_work (required) EVERY factor-state field of LQR::Workspace that
+ * sip_lqr_tree_factor() leaves there (lqr.hpp:109-135: W, K, G_factor, k per edge; V, F_factor, sqrt_delta,
+ * sqrt_delta_inv, v per node -- read by helpers.cpp:521-665), same arena layout: what the drop-in LQR class needs to
+ * run on the fused kernels by default.  G_factor / F_factor: the lower triangle holds Eigen's L, the entries above
+ * the diagonal their pre-factor values (Eigen::LLT factors in place, lqr.cpp:505, 697).  A second instantiation of
+ * the kernel, so sip_lqr_tree_factor_solve() keeps its register budget. */
+int sip_lqr_tree_factor_solve_workspace(const sip_lqr_tree_plan *plan, const double *d_input,
+                                        double *d_work, double *d_output, int32_t *d_status,
+                                        void *d_scratch, void *stream);
 const char *sip_lqr_tree_kernel_name(const sip_lqr_tree_plan *plan);
 
 /* Name of the kernel variant the plan dispatches to (static string). */

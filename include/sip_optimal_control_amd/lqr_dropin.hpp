@@ -366,6 +366,23 @@ public:
     return on;
   }
   void set_fused_chains(bool on) { fused_chains_ = on; }
+  // Trees and chains run on the fused size-class kernel (csrc/tree_qw16.hpp, every LQR::Workspace field written
+  // out) wherever it applies; true keeps them on the general engine (also: SIP_LQR_DROPIN_GENERAL=1).
+  static bool &default_general_engine() {
+    static bool on = [] {
+      const char *v = std::getenv("SIP_LQR_DROPIN_GENERAL");
+      return v != nullptr && v[0] == '1';
+    }();
+    return on;
+  }
+  void set_general_engine(bool on) {
+    general_engine_ = on;
+    gpu_.reset();
+  }
+  bool uses_fused_tree_kernel() {
+    OnDevice on_device(device_ordinal_);
+    return traversal_status_ == FactorStatus::SUCCESS && fast_chain() == nullptr && device().d_scratch != nullptr;
+  }
   bool uses_fused_chain_kernel() {
     OnDevice on_device(device_ordinal_);
     return fast_chain() != nullptr;
@@ -396,7 +413,11 @@ public:
     Device &d = device();
     gather_input(d);
     d.h2d(d.d_in, d.h_in);
-    check(sip_lqr_tree_factor(d.plan, d.d_in, d.d_ws, d.d_status, nullptr), "sip_lqr_tree_factor");
+    if (d.d_scratch != nullptr) // the fused size-class kernel, writing every LQR::Workspace field (tree_qw16.hpp)
+      check(sip_lqr_tree_factor_solve_workspace(d.plan, d.d_in, d.d_ws, d.d_out, d.d_status, d.d_scratch, nullptr),
+            "sip_lqr_tree_factor_solve_workspace");
+    else
+      check(sip_lqr_tree_factor(d.plan, d.d_in, d.d_ws, d.d_status, nullptr), "sip_lqr_tree_factor");
     int32_t st = 0;
     check_hip(hipMemcpy(&st, d.d_status, sizeof(st), hipMemcpyDeviceToHost), "status copy");
     d.d2h(d.h_ws, d.d_ws);
@@ -413,7 +434,11 @@ public:
     Device &d = device();
     gather_input(d);
     d.h2d(d.d_in, d.h_in);
-    check(sip_lqr_tree_solve(d.plan, d.d_in, d.d_ws, d.d_out, d.d_status, nullptr), "sip_lqr_tree_solve");
+    if (d.d_scratch != nullptr) // one fused sweep (it refactors: same matrices, same factor state)
+      check(sip_lqr_tree_factor_solve_workspace(d.plan, d.d_in, d.d_ws, d.d_out, d.d_status, d.d_scratch, nullptr),
+            "sip_lqr_tree_factor_solve_workspace");
+    else
+      check(sip_lqr_tree_solve(d.plan, d.d_in, d.d_ws, d.d_out, d.d_status, nullptr), "sip_lqr_tree_solve");
     d.d2h(d.h_out, d.d_out);
     d.d2h(d.h_ws, d.d_ws);
     const Dimensions &dims = input_.dimensions;
@@ -463,6 +488,7 @@ private:
   struct Device {
     sip_lqr_tree_plan *plan = nullptr;
     double *d_in = nullptr, *d_ws = nullptr, *d_out = nullptr;
+    void *d_scratch = nullptr; // non-null: the plan runs on the fused tree kernel
     int32_t *d_status = nullptr;
     std::vector<double> h_in, h_ws, h_out;
     int max_n = 0;
@@ -475,7 +501,7 @@ private:
         check_hip(hipMemcpy(dst.data(), src, dst.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H");
     }
     ~Device() {
-      for (void *p : {(void *)d_in, (void *)d_ws, (void *)d_out, (void *)d_status})
+      for (void *p : {(void *)d_in, (void *)d_ws, (void *)d_out, (void *)d_status, d_scratch})
         if (p != nullptr)
           (void)hipFree(p);
       sip_lqr_tree_plan_destroy(plan);
@@ -605,6 +631,11 @@ private:
     d->d_out = dev_alloc(d->h_out.size());
     check_hip(hipMalloc((void **)&d->d_status, sizeof(int32_t)), "hipMalloc");
     check_hip(hipMemset(d->d_status, 0xff, sizeof(int32_t)), "hipMemset");
+    // Default: the fused size-class kernel (state dims <= 15, control dims <= 8) with every LQR::Workspace field
+    // written out; set_general_engine(true) / SIP_LQR_DROPIN_GENERAL=1 keeps the general engine.
+    const size_t scratch = general_engine_ ? 0 : sip_lqr_tree_fused_scratch_bytes(d->plan);
+    if (scratch > 0)
+      check_hip(hipMalloc(&d->d_scratch, scratch), "hipMalloc");
     gpu_ = std::move(d);
     return *gpu_;
   }
@@ -673,6 +704,7 @@ private:
   std::unique_ptr<FastChain> fast_;
   int device_ordinal_ = default_device();
   bool fused_chains_ = default_fused_chains();
+  bool general_engine_ = default_general_engine();
 };
 
 } // namespace sip::optimal_control

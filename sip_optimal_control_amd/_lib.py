@@ -63,6 +63,7 @@ _SIGNATURES = {
     "sip_lqr_tree_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "sip_lqr_tree_fused_scratch_bytes": (ctypes.c_size_t, [_P]),
     "sip_lqr_tree_factor_solve": (ctypes.c_int, [_P] * 7),
+    "sip_lqr_tree_factor_solve_workspace": (ctypes.c_int, [_P] * 7),
     "sip_lqr_tree_kernel_name": (ctypes.c_char_p, [_P]),
     "sip_lqr_kernel_name": (ctypes.c_char_p, [_P]),
     "sip_lqr_version": (ctypes.c_char_p, []),

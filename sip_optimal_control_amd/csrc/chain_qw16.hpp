@@ -170,11 +170,12 @@ struct ChainLayout {
 // dl: delta_c one per lane (1.0 on lanes >= N).  tv: c - delta o v on the
 // vector lane, zeros elsewhere.  X returns S = F^{-1} (lanes < N) and, on the
 // vector lane, S D^{-1/2} tv.  Returns pivot failure.
-template <int N>
+// EXPORT (the fused tree kernel's LQR::Workspace outputs): Lt returns the factor of F as chol_ldl_dpp leaves it.
+template <int N, bool EXPORT = false>
 __device__ __forceinline__ bool node_factor(const double (&V)[N], const double dl,
                                             const int c, const double (&E)[N],
                                             const double (&tv)[N], double (&W)[N],
-                                            double (&X)[N]) {
+                                            double (&X)[N], double *Lt = nullptr) {
   const double sdi = rsqrt_nr(dl); // sqrt_delta_inv, lqr.cpp:482
   const double sd = dl * sdi;      // sqrt_delta,     lqr.cpp:481
   double S[N], A[N], rinv[N];
@@ -185,6 +186,8 @@ __device__ __forceinline__ bool node_factor(const double (&V)[N], const double d
     A[r] = __builtin_fma(S[r], V[r], E[r]); // I + D^1/2 V D^1/2, lqr.cpp:497-503
   });
   const bool fail = chol_ldl_dpp<N>(A, rinv, c); // LLT of lqr.cpp:505
+  if constexpr (EXPORT)
+    sfor<0, N>([&](auto ii) { Lt[decltype(ii)::value] = A[decltype(ii)::value]; });
   sfor<0, N>([&](auto ii) { X[decltype(ii)::value] = E[decltype(ii)::value]; });
   spreadv<N, false>(X, sdi, tv); // vector lane: D^{-1/2} (c - delta o v), lqr.cpp:539-541
   ldl_solve_dpp<N>(A, rinv, X); // F^{-1} [I | .], lqr.cpp:516-519, 542-545

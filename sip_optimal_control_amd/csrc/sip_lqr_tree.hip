@@ -138,12 +138,14 @@ int sip_lqr_tree_plan_create(int64_t batch, int num_edges, int root,
     auto node_fields = [&](sipamd::TreeStep &st, int j) {
       st.node = j, st.n = g.state_dims[j];
       st.oQ = g.oQ[j], st.oq = g.oq[j], st.oc = g.oc[j], st.od = g.od[j];
+      st.oV = g.oV[j], st.oF = g.oF[j], st.osd = g.osd[j], st.osdi = g.osdi[j], st.ov = g.ov[j];
     };
     auto edge_fields = [&](sipamd::TreeStep &st, int e) {
       const int ch = g.children[e];
       st.edge = e, st.child = ch, st.nc = g.state_dims[ch], st.m = g.control_dims[e];
       st.oA = g.oA[e], st.oB = g.oB[e], st.oM = g.oM[e], st.oR = g.oR[e], st.orr = g.orr[e], st.odc = g.od[ch];
       st.oK = g.oK[e], st.ok = g.ok[e], st.ou = g.ou[e], st.oxc = g.ox[ch], st.oyc = g.oy[ch];
+      st.oW = g.oW[e], st.oG = g.oG[e];
       st.oxp = g.ox[g.parents[e]];
     };
     int finished = -1; // node finished by the previous backward step
@@ -296,9 +298,10 @@ size_t sip_lqr_tree_fused_scratch_bytes(const sip_lqr_tree_plan *plan) {
   return (plan != nullptr && plan->fused != nullptr) ? plan->scratch_bytes : 0;
 }
 
-int sip_lqr_tree_factor_solve(const sip_lqr_tree_plan *plan, const double *d_input, double *d_work, double *d_output,
-                              int32_t *d_status, void *d_scratch, void *stream) {
-  if (plan == nullptr || d_status == nullptr)
+namespace {
+int tree_factor_solve_impl(const sip_lqr_tree_plan *plan, const double *d_input, double *d_work, double *d_output,
+                           int32_t *d_status, void *d_scratch, void *stream, const bool workspace) {
+  if (plan == nullptr || d_status == nullptr || (workspace && d_work == nullptr))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   if (plan->topology_status != SIP_LQR_SUCCESS || plan->fused == nullptr) { // general engine, two launches
     const int rc = sip_lqr_tree_factor(plan, d_input, d_work, d_status, stream);
@@ -313,13 +316,25 @@ int sip_lqr_tree_factor_solve(const sip_lqr_tree_plan *plan, const double *d_inp
     return SIP_LQR_ERR_HIP;
   hipStream_t s = (hipStream_t)stream;
   char *w = (char *)d_scratch;
-  const hipError_t e = plan->fused->launch(plan->sched, d_input, d_output, d_work, (double *)w,
-                                           (double *)(w + plan->at_spill), d_status, (long)plan->batch, s);
+  const auto launch = workspace ? plan->fused->launch_export : plan->fused->launch;
+  const hipError_t e = launch(plan->sched, d_input, d_output, d_work, (double *)w, (double *)(w + plan->at_spill),
+                              d_status, (long)plan->batch, s);
   if (e != hipSuccess) {
     std::fprintf(stderr, "sip_lqr_tree_factor_solve: %s\n", hipGetErrorString(e));
     return SIP_LQR_ERR_HIP;
   }
   return SIP_LQR_OK;
+}
+} // namespace
+
+int sip_lqr_tree_factor_solve(const sip_lqr_tree_plan *plan, const double *d_input, double *d_work, double *d_output,
+                              int32_t *d_status, void *d_scratch, void *stream) {
+  return tree_factor_solve_impl(plan, d_input, d_work, d_output, d_status, d_scratch, stream, false);
+}
+
+int sip_lqr_tree_factor_solve_workspace(const sip_lqr_tree_plan *plan, const double *d_input, double *d_work,
+                                        double *d_output, int32_t *d_status, void *d_scratch, void *stream) {
+  return tree_factor_solve_impl(plan, d_input, d_work, d_output, d_status, d_scratch, stream, true);
 }
 
 } // extern "C"

@@ -5,14 +5,16 @@
 namespace sipamd {
 
 namespace {
-template <int N, int M>
+template <int N, int M, bool EXPORT>
 hipError_t launch(const TreeSchedule &ts, const double *input, double *output, double *work, double *pgains,
                   double *spill, int32_t *status, long batch, hipStream_t s) {
-  hipLaunchKernelGGL((tree_factor_solve_qw16<N, M>), dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, s, ts, input,
-                     output, work, pgains, spill, (int *)status, batch);
+  if (EXPORT && work == nullptr)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL((tree_factor_solve_qw16<N, M, EXPORT>), dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, s, ts,
+                     input, output, work, pgains, spill, (int *)status, batch);
   return hipGetLastError();
 }
-#define TREE_CLASS(N, M) {N, M, "tree_factor_solve_qw16<" #N "," #M ">/f64", &launch<N, M>}
+#define TREE_CLASS(N, M) {N, M, "tree_factor_solve_qw16<" #N "," #M ">/f64", &launch<N, M, false>, &launch<N, M, true>}
 // sorted by cost: the first class that holds the largest node and the largest control wins
 const TreeClass kClasses[] = {TREE_CLASS(4, 2),  TREE_CLASS(6, 3),  TREE_CLASS(8, 4),  TREE_CLASS(10, 4),
                               TREE_CLASS(12, 4), TREE_CLASS(15, 4), TREE_CLASS(15, 8)};

@@ -25,7 +25,9 @@
 // 16-lane row: with a batch that fills the machine (4 problems per wavefront) sibling parallelism
 // inside a problem has nothing left to fill.
 //
-// Inputs, outputs and (optionally) K, k: the tree-native arenas of include/sip_lqr_amd.h.  Internal
+// Inputs, outputs and (optionally) the factor state of LQR::Workspace (lqr.hpp:109-135: W, K, G_factor, k per
+// edge; V, F_factor, sqrt_delta, sqrt_delta_inv, v per node -- what helpers.cpp:521-665 reads): the tree-native
+// arenas of include/sip_lqr_amd.h.  Internal
 // scratch (per problem, doubles, padded to the size class):
 //   gains: edge e: K (M x N) | k (M)        spill: node i: S | g | h | t | v
 #pragma once
@@ -51,6 +53,8 @@ struct TreeStep {
   long oQ, oq, oc, od;             // input arena, of `node`
   long oA, oB, oM, oR, orr, odc;   // input arena, of the edge; delta of the child
   long oK, ok;                     // work arena: K, k of the edge
+  long oW, oG;                     // work arena: W, G_factor of the edge (LQR::Workspace, lqr.hpp:109-135)
+  long oV, oF, osd, osdi, ov;      // work arena: V, F_factor, sqrt_delta, sqrt_delta_inv, v of `node`
   long ou, oxc, oyc, oxp;          // output arena: u of the edge, x / y of the child, x of the parent
 };
 enum {
@@ -73,7 +77,10 @@ struct TreeLayout {
   static constexpr int WS = N * N + 4 * N; // S | g | h | t | v
 };
 
-template <int N, int M>
+// EXPORT: also write W, G_factor (edges) and V, F_factor, sqrt_delta, sqrt_delta_inv, v (nodes) of LQR::Workspace
+// into the work arena (which must then be given): a second instantiation, so that the kernel behind
+// sip_lqr_tree_factor_solve keeps its registers.
+template <int N, int M, bool EXPORT = false>
 __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
     const TreeSchedule ts, const double *__restrict__ in_all, double *__restrict__ out_all,
     double *__restrict__ work_all /* may be null: K, k not wanted */, double *__restrict__ gains,
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
     ZERO[decltype(ii)::value] = 0.0;
   });
 
+  auto E_of = [&](const int k) { return c == k ? 1.0 : 0.0; };
   // Column `col` of a column-major rows x cols block, padded to N rows:
   // dst[r] = on && col < cols && r < rows ? blk[r + rows * col] : fill[r].  Every load is issued
   // unconditionally from a clamped (always readable) address and the padding is selected afterwards:
@@ -134,7 +142,9 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
 #ifdef SIP_TREE_NO_PREFETCH
   constexpr bool kPrefetch = false;
 #else
-  constexpr bool kPrefetch = N * (N + 2 * M) <= 400;
+  // (nor in the workspace-export instantiation of the 15-state classes, which spills: scratch traffic and LDS-DMA
+  // share vmcnt, tools/check_dpp_hazards.py)
+  constexpr bool kPrefetch = N * (N + 2 * M) <= 400 && !(EXPORT && N >= 15);
 #endif
   auto prefetch = [&](const double *span, const long len, auto groups) {
     if constexpr (kPrefetch) {
@@ -224,6 +234,14 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
         G[decltype(jj)::value] = pre.g[decltype(jj)::value];
         H[decltype(jj)::value] = pre.h[decltype(jj)::value];
       });
+      if (EXPORT && valid && c < st.nc) { // LQR::Workspace::W of the edge (nc x nc, column-major)
+        double *dst = work + st.oW + (long)st.nc * c;
+        sfor<0, N>([&](auto ii) {
+          constexpr int r = decltype(ii)::value;
+          if (r < st.nc)
+            dst[r] = W[r];
+        });
+      }
       rank1x<N, N, true>(F, W, Aaug); // [F | g] = W [A | t] + [0 | v]  (lqr.cpp:703, :780-781)
       if (valid && isV)
         sfor<0, N>([&](auto ii) { slot[N * N + decltype(ii)::value] = F[decltype(ii)::value]; }); // g of the child
@@ -231,9 +249,24 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
       sfor<0, M>([&](auto jj) { Hc[decltype(jj)::value] = 0.0; });
       spreadx<M, N, false>(Hc, pre.b, W);
       rank1x<M, N, true>(G, Hc, pre.b);
+      double G0[M]; // export only: the entries above the diagonal keep their pre-factor values (Eigen's in-place LLT)
+      if constexpr (EXPORT)
+        sfor<0, M>([&](auto jj) { G0[decltype(jj)::value] = G[decltype(jj)::value]; });
       const bool gfail = chol_ldl_dpp<M>(G, rinvG, c); // lqr.cpp:696-701
       if (stat == 0 && gfail)
         stat = 3; // G_FACTORIZATION_FAILURE
+      if (EXPORT && valid && c < m) {
+        // LQR::Workspace::G_factor: lower triangle L of G = L L^T; the kernel holds Lt(i, c) = L(i, c) L(c, c)
+        double dc = 0.0;
+        sfor<0, M>([&](auto jj) { dc = __builtin_fma(E_of(decltype(jj)::value), G[decltype(jj)::value], dc); }); // pivot d_c
+        const double li = rsqrt_nr(dc); // 1 / L(c, c)
+        double *dst = work + st.oG + (long)m * c;
+        sfor<0, M>([&](auto jj) {
+          constexpr int q = decltype(jj)::value;
+          if (q < m)
+            dst[q] = q >= c ? G[q] * li : G0[q];
+        });
+      }
       spreadx<M, N, false>(H, pre.b, F); // [H | h] = [M^T | r] + B^T [F | g]  (:704-705, :783-784)
       sfor<0, M>([&](auto jj) { K[decltype(jj)::value] = H[decltype(jj)::value]; });
       ldl_solve_dpp<M>(G, rinvG, K); // [K | k] = -G^{-1} [H | h]  (:707-713, :785-791)
@@ -275,7 +308,39 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
           mine[N * N + 3 * N + r] = V[r];
         });
       double X[N];
-      const bool ffail = node_factor<N>(V, dl, c, E, tv, W, X);
+      bool ffail;
+      if constexpr (EXPORT) { // the same factorization, with the factor state of LQR::Workspace written out
+        double Lt[N];
+        ffail = node_factor<N, true>(V, dl, c, E, tv, W, X, Lt);
+        if (valid && c < n) {
+          const double sdi = rsqrt_nr(dl), sd = dl * sdi;
+          work[st.osd + c] = sd, work[st.osdi + c] = sdi;
+          double dc = 0.0, sdr[N];
+          sfor<0, N>([&](auto ii) {
+            dc = __builtin_fma(E[decltype(ii)::value], Lt[decltype(ii)::value], dc); // pivot d_c = L(c, c)^2
+            sdr[decltype(ii)::value] = 0.0;
+          });
+          spread<N, false, true>(sdr, sd, sd); // sd_r sd_c
+          const double li = rsqrt_nr(dc);
+          double *dv = work + st.oV + (long)n * c, *df = work + st.oF + (long)n * c;
+          sfor<0, N>([&](auto ii) {
+            constexpr int r = decltype(ii)::value;
+            if (r < n) {
+              dv[r] = V[r];
+              // F_factor: L below and on the diagonal, the pre-factor I + D^1/2 V D^1/2 above (lqr.cpp:497-505)
+              df[r] = r >= c ? Lt[r] * li : __builtin_fma(sdr[r], V[r], E[r]);
+            }
+          });
+        }
+        if (valid && isV)
+          sfor<0, N>([&](auto ii) {
+            constexpr int r = decltype(ii)::value;
+            if (r < n)
+              work[st.ov + r] = V[r]; // the affine column: v of the node
+          });
+      } else {
+        ffail = node_factor<N>(V, dl, c, E, tv, W, X);
+      }
       if (stat == 0 && ffail)
         stat = 2; // F_FACTORIZATION_FAILURE
       if (valid && isV) // h = S D^{-1/2} (c - delta o v)

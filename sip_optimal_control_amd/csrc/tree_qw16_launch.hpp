@@ -13,6 +13,9 @@ struct TreeClass {
   const char *name;
   hipError_t (*launch)(const TreeSchedule &ts, const double *input, double *output, double *work, double *pgains,
                        double *spill, int32_t *status, long batch, hipStream_t s);
+  // the same sweep that also writes every LQR::Workspace field into the work arena (sip_lqr_tree_factor_solve_workspace)
+  hipError_t (*launch_export)(const TreeSchedule &ts, const double *input, double *output, double *work, double *pgains,
+                              double *spill, int32_t *status, long batch, hipStream_t s);
 };
 
 // Smallest size class that holds a tree whose largest state / control dimensions are max_n / max_m;

@@ -95,19 +95,21 @@ class BatchedTreeLQR:
     def kernel_name(self):
         return self._lib.sip_lqr_tree_kernel_name(self._plan).decode()
 
-    def factor_solve(self):
+    def factor_solve(self, workspace=False):
         """factor_with_status() + solve() as one fused sweep (size-class kernel of csrc/tree_qw16.hpp
-        where the tree fits one, the general engine otherwise): output, status, K and k of `work`."""
+        where the tree fits one, the general engine otherwise): output, status, K and k of `work`;
+        workspace=True: every LQR::Workspace field of `work` (sip_lqr_tree_factor_solve_workspace)."""
         s = torch.cuda.current_stream(self.device)
+        entry = self._lib.sip_lqr_tree_factor_solve_workspace if workspace else self._lib.sip_lqr_tree_factor_solve
         need = self._lib.sip_lqr_tree_fused_scratch_bytes(self._plan)
         if getattr(self, "_scratch", None) is None or self._scratch.numel() < need:
             self._scratch = torch.empty(max(1, need), dtype=torch.uint8, device=self.device)
-        _check(self._lib.sip_lqr_tree_factor_solve(self._plan, ctypes.c_void_p(self.input.data_ptr()),
-                                                   ctypes.c_void_p(self.work.data_ptr()),
-                                                   ctypes.c_void_p(self.output.data_ptr()),
-                                                   ctypes.c_void_p(self.status.data_ptr()),
-                                                   ctypes.c_void_p(self._scratch.data_ptr()),
-                                                   ctypes.c_void_p(s.cuda_stream)), "sip_lqr_tree_factor_solve")
+        _check(entry(self._plan, ctypes.c_void_p(self.input.data_ptr()),
+                     ctypes.c_void_p(self.work.data_ptr()),
+                     ctypes.c_void_p(self.output.data_ptr()),
+                     ctypes.c_void_p(self.status.data_ptr()),
+                     ctypes.c_void_p(self._scratch.data_ptr()),
+                     ctypes.c_void_p(s.cuda_stream)), "sip_lqr_tree_factor_solve")
         return self.output, self.status
 
     def solve(self):

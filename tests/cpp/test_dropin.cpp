@@ -553,6 +553,71 @@ int main() {
          }
          ws.free(3);
        }},
+      {"LQR.FusedTreeKernelIsTheDefault (every LQR::Workspace field, against the general engine)", [] {
+         // Trees / chains with state dims <= 15, control dims <= 8 run on the fused size-class kernel by default and
+         // leave W, K, G_factor, k, V, F_factor, sqrt_delta(_inv), v (lqr.hpp:109-135; read by helpers.cpp:521-665) in
+         // the caller's workspace; the same object on the general engine (set_general_engine) must agree on all of
+         // them (G_factor / F_factor: the lower triangle, which is all triangularView<Lower> reads).
+         for (int which = 0; which < 4; ++which) {
+           auto p = which == 0 ? five_node_tree() : which == 1 ? branch_tree() : which == 2 ? variable_dimension_branch()
+                                                                                            : nonuniform_diagonal_delta();
+           auto input = p.input();
+           LQR::Workspace wf, wg;
+           wf.reserve(input.dimensions, input.topology);
+           wg.reserve(input.dimensions, input.topology);
+           {
+             auto fused = LQR(input, wf);
+             auto general = LQR(input, wg);
+             fused.set_general_engine(false); // (whatever SIP_LQR_DROPIN_GENERAL says)
+             general.set_general_engine(true);
+             CHECK(fused.uses_fused_tree_kernel());
+             CHECK(!general.uses_fused_tree_kernel());
+             CHECK(fused.factor_with_status() == Status::SUCCESS);
+             CHECK(general.factor_with_status() == Status::SUCCESS);
+             Solution sf(p), sg(p);
+             auto of = sf.output(), og = sg.output();
+             fused.solve(of);
+             fused.solve(of); // repeatable (lqr_test.cpp:431-450)
+             general.solve(og);
+             CHECK(kkt_residual(p, sf) < 1e-12);
+             double worst = 0.0;
+             auto cmp = [&](const double *a, const double *b, int rows, int cols, bool lower_only) {
+               double scale = 1.0;
+               for (int k = 0; k < rows * cols; ++k)
+                 scale = std::fmax(scale, std::fabs(b[k]));
+               for (int col = 0; col < cols; ++col)
+                 for (int row = lower_only ? col : 0; row < rows; ++row)
+                   worst = std::fmax(worst, std::fabs(a[row + rows * col] - b[row + rows * col]) / scale);
+             };
+             for (int e = 0; e < p.E(); ++e) {
+               const int np = p.state_dims[p.parents[e]], nc = p.state_dims[p.children[e]], m = p.control_dims[e];
+               cmp(wf.W[e], wg.W[e], nc, nc, false);
+               cmp(wf.K[e], wg.K[e], m, np, false);
+               cmp(wf.G_factor[e], wg.G_factor[e], m, m, true);
+               cmp(wf.k[e], wg.k[e], m, 1, false);
+             }
+             for (int j = 0; j < p.N(); ++j) {
+               const int n = p.state_dims[j];
+               cmp(wf.V[j], wg.V[j], n, n, false);
+               cmp(wf.F_factor[j], wg.F_factor[j], n, n, true);
+               cmp(wf.sqrt_delta[j], wg.sqrt_delta[j], n, 1, false);
+               cmp(wf.sqrt_delta_inv[j], wg.sqrt_delta_inv[j], n, 1, false);
+               cmp(wf.v[j], wg.v[j], n, 1, false);
+             }
+             CHECK(worst < 1e-12);
+             if (worst >= 1e-12)
+               std::printf("    problem %d: worst relative workspace difference %.3e\n", which, worst);
+             // statuses through the fused default
+             const double keep = p.delta[1][0];
+             p.delta[1][0] = 0.0;
+             CHECK(fused.factor_with_status() == Status::INVALID_DELTA);
+             p.delta[1][0] = keep;
+             CHECK(fused.factor_with_status() == Status::SUCCESS);
+           }
+           wf.free(p.E());
+           wg.free(p.E());
+         }
+       }},
       {"LQR.FusedChainSwitch (adapter addition: uniform chains on the fused kernels, explicit device)", [] {
          // the reference's chain fixture (lqr_test.cpp:229-247) through sip_lqr_factor / sip_lqr_solve:
          // same statuses, same solution (KKT residual < 1e-12), K and k in the caller's workspace

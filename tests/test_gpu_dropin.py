@@ -10,16 +10,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cpp_dropin_suite():
+@pytest.mark.parametrize("engine", ["fused (default)", "general"])
+def test_cpp_dropin_suite(engine):
+    """The reference's 14 tests + the adapter's own: once as a user gets the class (trees and chains on the fused
+    size-class kernel wherever it applies, every LQR::Workspace field written out) and once held to the general
+    engine (SIP_LQR_DROPIN_GENERAL=1)."""
     import __graft_entry__ as entry
     entry.build_hip()
     exe = entry.build_dropin_test()
-    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    env.pop("SIP_LQR_DROPIN_GENERAL", None)
+    if engine == "general":
+        env["SIP_LQR_DROPIN_GENERAL"] = "1"
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     print(proc.stdout)
     print(proc.stderr)
     assert proc.returncode == 0, proc.stdout[-3000:]
     assert "0 failures" in proc.stdout
-    assert proc.stdout.count("[  OK  ]") >= 18
+    assert proc.stdout.count("[  OK  ]") >= 19
 
 
 def test_cpp_callback_provider_suite():

@@ -313,3 +313,79 @@ def test_trees_beyond_the_size_classes_fall_back_to_the_general_engine(oracle_li
     _check_against_oracle(oracle_lib, s, [prob["blocks"]], tol=1e-10)
     monkeypatch.setenv("SIP_LQR_TREE", "general")
     assert _solver(rp.branch_tree()).kernel_name == "tree_generic/f64"
+
+
+def test_fused_sweep_writes_every_workspace_field(oracle_lib):
+    """sip_lqr_tree_factor_solve_workspace: the fused size-class kernel leaves W, K, G_factor, k (edges) and V,
+    F_factor, sqrt_delta, sqrt_delta_inv, v (nodes) of LQR::Workspace (lqr.hpp:109-135) in the work arena, as
+    sip_lqr_tree_factor + sip_lqr_tree_solve of the general engine do -- what lets the drop-in LQR class run on the
+    fused kernels by default (helpers.cpp:521-665 reads those fields).  Whole arenas compared (G_factor / F_factor:
+    lower triangles; above the diagonal both keep the pre-factor values of Eigen's in-place LLT), random trees in
+    three size classes with zero-dimensional nodes, the reference's fixtures, a batch of 6."""
+    rng = np.random.default_rng(5)
+    cases = [dict(parents=p["parents"], children=p["children"], state_dims=p["state_dims"],
+                  control_dims=p["control_dims"], probs=[p["blocks"]])
+             for p in (rp.five_node_variable_tree_eigen(), rp.branch_tree(), rp.variable_dimension_branch(),
+                       rp.nonuniform_diagonal_delta())]
+    for nmax, mmax, N in [(5, 2, 8), (10, 4, 7), (15, 8, 5)]:
+        parents = [int(rng.integers(0, e + 1)) for e in range(N - 1)]
+        sd = [int(rng.integers(0, nmax + 1)) for _ in range(N)]
+        sd[int(rng.integers(0, N))] = nmax
+        cd = [int(rng.integers(1, mmax + 1)) for _ in range(N - 1)]
+        cd[0] = mmax
+        probs = []
+        for b in range(6):
+            blocks = {k: [] for k in ("Q", "M", "R", "q", "r", "A", "B", "c", "delta")}
+            for n in sd:
+                S = rng.normal(size=(n, n))
+                blocks["Q"].append(S.T @ S + 1e-3 * np.eye(n))
+                blocks["q"].append(rng.normal(size=n)); blocks["c"].append(rng.normal(size=n))
+                blocks["delta"].append(1e-3 + 0.1 * rng.random(n))
+            for e, m in enumerate(cd):
+                np_, nc = sd[parents[e]], sd[e + 1]
+                G = rng.normal(size=(m, m))
+                blocks["A"].append(0.3 * rng.normal(size=(nc, np_))); blocks["B"].append(0.3 * rng.normal(size=(nc, m)))
+                blocks["M"].append(0.05 * rng.normal(size=(np_, m))); blocks["R"].append(G.T @ G + 1.01 * np.eye(m))
+                blocks["r"].append(rng.normal(size=m))
+            probs.append(blocks)
+        cases.append(dict(parents=parents, children=list(range(1, N)), state_dims=sd, control_dims=cd, probs=probs))
+    for case in cases:
+        probs = case.pop("probs")
+        s = _solver(case, batch=len(probs))
+        assert "tree_factor_solve_qw16" in s.kernel_name
+        s.pack(probs)
+        s.work.zero_()
+        s.factor(); s.solve()
+        torch.cuda.synchronize()
+        want, want_out = s.work.clone().cpu().numpy(), s.output.clone()
+        s.work.zero_(); s.output.zero_()
+        s.factor_solve(workspace=True)
+        torch.cuda.synchronize()
+        got = s.work.cpu().numpy()
+        assert float((s.output - want_out).abs().max()) <= 1e-10 * max(1.0, float(want_out.abs().max()))
+        sd, cd, par, ch = case["state_dims"], case["control_dims"], case["parents"], case["children"]
+        max_n = max(sd)
+
+        def close(a, b, what):
+            scale = max(1.0, float(np.abs(b).max(initial=0.0)))
+            assert float(np.abs(a - b).max(initial=0.0)) <= 1e-10 * scale, what
+
+        for b in range(len(probs)):
+            for e in range(len(cd)):
+                np_, nc, m = sd[par[e]], sd[ch[e]], cd[e]
+                o = s.offset(1, 1, e)
+                close(got[b, o:o + nc * nc], want[b, o:o + nc * nc], ("W", e))
+                o += max_n * max_n
+                close(got[b, o:o + m * np_], want[b, o:o + m * np_], ("K", e))
+                o += m * np_
+                tri = np.tril(np.ones((m, m), dtype=bool)).T.reshape(-1)        # column-major lower triangle
+                close(got[b, o:o + m * m][tri], want[b, o:o + m * m][tri], ("G_factor", e))
+                o += m * m
+                close(got[b, o:o + m], want[b, o:o + m], ("k", e))
+            for j, n in enumerate(sd):
+                o = s.offset(1, 0, j)
+                close(got[b, o:o + n * n], want[b, o:o + n * n], ("V", j))
+                tri = np.tril(np.ones((n, n), dtype=bool)).T.reshape(-1)
+                close(got[b, o + n * n:o + 2 * n * n][tri], want[b, o + n * n:o + 2 * n * n][tri], ("F_factor", j))
+                close(got[b, o + 2 * n * n:o + 2 * n * n + 3 * n], want[b, o + 2 * n * n:o + 2 * n * n + 3 * n],
+                      ("sqrt_delta | sqrt_delta_inv | v", j))
