@@ -51,6 +51,10 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=5,
                     help="timed blocks of --steps steps each; the line reports the MEDIAN block "
                          "(ms_per_step, value) with min / max beside it")
+    ap.add_argument("--layout", default="auto", choices=["auto", "full", "sym"],
+                    help="layout of `mats` in HBM (include/sip_lqr_amd.h): full squares as LQR::Input holds them, or "
+                         "Q and R as packed lower triangles (SIP_LQR_LAYOUT_SYMMETRIC); auto: sym where the shape has "
+                         "the kernel and the launch is bandwidth-bound (c3), and the line then carries the full-layout figure too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target wall time of each cpu_baseline leg")
@@ -296,7 +300,18 @@ def main():
     esize = 8 if dt == "f64" else 4
     shape = ChainShape(n, m, T)
     mats, vecs = synthetic.make_chain_batch(shape, batch, seed=1234 + rank, device=device, dtype=dtype)
-    solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device=device)
+    full_mats, full_solver = mats, None
+    # (auto: where the launch is bandwidth-bound; at batch 1024 -- one wavefront per CU, latency-bound -- the packed
+    # triangles' address arithmetic costs 1 % instead of saving 6 %)
+    sym = args.layout == "sym" or (args.layout == "auto" and dt == "f64" and (n, m) == (12, 4) and batch >= 2048)
+    if sym:
+        # the same problems with Q and R as packed lower triangles (the reference takes Q symmetric, lqr.cpp:658,
+        # and reads the lower triangle of R only, lqr.cpp:697): 576 B less per problem-stage at (12, 4)
+        import numpy as np  # noqa: F401
+        idx = torch.from_numpy(shape.packed().pack_index()).to(device)
+        mats = full_mats[:, idx].contiguous()
+        full_solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device=device)
+    solver = BatchedChainLQR(n, m, T, batch, dtype=dtype, device=device, symmetric=sym)
     sol = solver.empty_sol()
     gather = world > 1 and not args.no_gather
     modes = [] if not gather else (["allgather", "mesh"] if args.gather_mode == "both" else [args.gather_mode])
@@ -309,7 +324,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def run(ag):
+    def run(ag, solver=solver, mats=mats):
         """W warmup steps, then `blocks` timed blocks of exactly K steps, each between barrier +
         synchronize fences; per block the max-over-ranks seconds.  Returns (list of block seconds,
         mean kernel ms of this rank over all timed steps)."""
@@ -369,6 +384,10 @@ def main():
         del ag
     if gather or not results:  # the same K steps without the exchange: independent shards, the compute-only bound
         results["no_gather"] = summary(*run(None))
+    full_layout = None
+    if sym and world == 1:  # the same sweeps on the full squares, timed the same way, beside the headline
+        full_layout = summary(*run(None, full_solver, full_mats))
+        full_layout["kernel"] = full_solver.kernel_name
     best = max(modes, key=lambda k: results[k]["value"]) if modes else "no_gather"
     head = results[best]
     elapsed, kernel_ms = head["ms_per_step"] * 1e-3 * args.steps, head["kernel_ms"]
@@ -397,7 +416,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: batch={batch}/GPU x horizon={T}, nx={n}, nu={m}, {dt}, "
-                            f"chain, fused factor+solve" +
+                            f"chain, fused factor+solve, mats layout: " +
+                            ("Q, R as packed lower triangles (SIP_LQR_LAYOUT_SYMMETRIC)" if sym else "full squares") +
                             (f", all-gather of gains ({best} form) over {backend}" if gather else ""),
                 "global_batch": world * batch, "horizon": T, "nx": n, "nu": m,
                 "parallelism": f"batch-sharded x{world}" +
@@ -432,8 +452,13 @@ def main():
             for mode in modes:
                 out["gather"][mode] = results[mode]
             out["no_gather"] = results["no_gather"]
+        if full_layout is not None:
+            full_layout["roofline_frac"] = alg_bytes * batch / (full_layout["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["full_layout"] = full_layout
+            out["roofline"]["bytes_per_launch_in_this_layout"] = batch * esize * (
+                shape.packed().mats_len + 2 * shape.vecs_len + shape.gains_len)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(shape, mats, vecs, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(shape, full_mats, vecs, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

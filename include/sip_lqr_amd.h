@@ -89,6 +89,15 @@ enum {
 };
 
 enum { SIP_LQR_F64 = 0, SIP_LQR_F32 = 1 };
+/* Layout of `mats` (see "Packed chain layout" above):
+ *   FULL       Q (n x n) and R (m x m) as full column-major squares, as LQR::Input holds them;
+ *   SYMMETRIC  Q and R as their lower triangles packed by columns (column c: rows c .. n-1): n (n + 1) / 2 and
+ *              m (m + 1) / 2 scalars.  The reference reads both triangles of a Q it takes to be symmetric
+ *              (`V = Q`, lqr.cpp:658) and only the lower one of R (Eigen::LLT of G, lqr.cpp:697 -- G's strictly
+ *              upper part comes from R + (B^T W) B there, the kernels here use the symmetric counterpart), so the
+ *              upper triangles are redundant bytes of a bandwidth-bound sweep: 576 of the 7 840 B a problem-stage
+ *              moves at n = 12, m = 4.  Everything else ([Q | delta] then [A | B | M | R] per stage) is unchanged. */
+enum { SIP_LQR_LAYOUT_FULL = 0, SIP_LQR_LAYOUT_SYMMETRIC = 1 };
 
 typedef struct sip_lqr_plan sip_lqr_plan;
 /* Threading: like the reference (no globals; distinct LQR + Workspace pairs are independent, a
@@ -104,6 +113,16 @@ typedef struct sip_lqr_plan sip_lqr_plan;
  * wavefront per problem, see sip_lqr_kernel_name()). */
 int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
                         int device, sip_lqr_plan **plan);
+/* The same with a layout of `mats` other than FULL.  SIP_LQR_LAYOUT_SYMMETRIC: fp64 shapes with a symmetric-packed
+ * fused kernel (sip_lqr_kernel_name() carries "sym": LDS-staged kernels with even n and m whose blocks stay whole
+ * 16-byte pieces, the reference's n = 12, m = 4 benchmark shape among them); SIP_LQR_ERR_UNSUPPORTED otherwise.
+ * sip_lqr_mats_len / _bytes, sip_lqr_pack_problem and every compute entry point follow the plan's layout;
+ * sip_lqr_factor_solve_split and the one-sweep sip_lqr_solve_multi are FULL-layout only (solve_multi then goes
+ * column by column). */
+int sip_lqr_plan_create_layout(int dtype, int64_t batch, int T, int n, int m, int device, int layout,
+                               sip_lqr_plan **plan);
+int sip_lqr_plan_layout(const sip_lqr_plan *plan);
+
 void sip_lqr_plan_destroy(sip_lqr_plan *plan);
 
 /* Sizes, in bytes, of the whole-batch buffers.  Replace

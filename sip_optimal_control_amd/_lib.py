@@ -26,6 +26,9 @@ _PP = ctypes.POINTER(ctypes.c_void_p)
 _SIGNATURES = {
     "sip_lqr_plan_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, _PP]),
+    "sip_lqr_plan_create_layout": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, _PP]),
+    "sip_lqr_plan_layout": (ctypes.c_int, [_P]),
     "sip_lqr_plan_destroy": (None, [_P]),
     "sip_lqr_mats_bytes": (ctypes.c_size_t, [_P]),
     "sip_lqr_vecs_bytes": (ctypes.c_size_t, [_P]),

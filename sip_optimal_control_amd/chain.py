@@ -36,16 +36,18 @@ def _check(code, what):
 class BatchedChainLQR:
     """`batch` independent chain problems of horizon T, state dim n, control dim m."""
 
-    def __init__(self, n, m, T, batch, dtype=torch.float64, device="cuda:0"):
+    def __init__(self, n, m, T, batch, dtype=torch.float64, device="cuda:0", symmetric=False):
+        """symmetric=True: `mats` in SIP_LQR_LAYOUT_SYMMETRIC (Q, R as packed lower triangles; ChainShape.pack_index
+        converts a full-layout batch); raises for shapes without a symmetric-packed kernel."""
         self._lib = load_library()
-        self.shape = ChainShape(n, m, T)
+        self.shape = ChainShape(n, m, T, symmetric=bool(symmetric))
         self.batch = int(batch)
         self.dtype = dtype
         self.device = resolve_device(device)  # explicit ordinal; raises without a HIP device
         handle = ctypes.c_void_p()
-        _check(self._lib.sip_lqr_plan_create(_DTYPES[dtype], self.batch, T, n, m,
-                                             self.device.index, ctypes.byref(handle)),
-               f"sip_lqr_plan_create(n={n}, m={m}, T={T}, {dtype})")
+        _check(self._lib.sip_lqr_plan_create_layout(_DTYPES[dtype], self.batch, T, n, m, self.device.index,
+                                                    1 if symmetric else 0, ctypes.byref(handle)),
+               f"sip_lqr_plan_create_layout(n={n}, m={m}, T={T}, {dtype}, symmetric={bool(symmetric)})")
         self._plan = handle
         esize = torch.empty((), dtype=dtype).element_size()
         assert self._lib.sip_lqr_mats_len(handle) == self.shape.mats_len

@@ -155,11 +155,17 @@ __device__ __forceinline__ void ldl_solve_dpp(const double (&Lt)[S],
   });
 }
 
-template <int N, int M>
+// SYM: the symmetric-packed layout (SIP_LQR_LAYOUT_SYMMETRIC, include/sip_lqr_amd.h): Q and R are stored as their
+// lower triangles packed by columns (column c: rows c .. n-1), n (n + 1) / 2 and m (m + 1) / 2 scalars -- the
+// reference reads both triangles of a symmetric Q (lqr.cpp:658) and only the lower one of R (Eigen::LLT, :697), so
+// the strictly upper parts are redundant bytes of a bandwidth-bound kernel (576 of 7 840 B per problem-stage at C3).
+template <int N, int M, bool SYM = false>
 struct ChainLayout {
   // scalars per stage block (see include/sip_lqr_amd.h, "Packed chain layout")
-  static constexpr int NODE = N * N + N;               // Q | delta
-  static constexpr int EDGE = N * N + 2 * N * M + M * M; // A | B | M | R
+  static constexpr int QLEN = SYM ? N * (N + 1) / 2 : N * N;
+  static constexpr int RLEN = SYM ? M * (M + 1) / 2 : M * M;
+  static constexpr int NODE = QLEN + N;                  // Q | delta
+  static constexpr int EDGE = N * N + 2 * N * M + RLEN;  // A | B | M | R
   static constexpr int VNODE = 2 * N;                  // q | c   (x | y)
   static constexpr int VEDGE = M;                      // r       (u)
   static constexpr int GAIN = M * N + M;               // K | k
@@ -382,9 +388,11 @@ struct StageDmaRows {
 // SPLIT (the Newton-KKT step, sip_lqr_factor_solve_split): A | B are not part of the mats stage
 // block -- [Q | delta | M | R] is -- and stream from a second array (the dynamics Jacobians where the
 // model callback left them), as an image of their own behind the mats image.
-template <int N, int M, bool WPACK, bool SPLIT = false>
+template <int N, int M, bool WPACK, bool SPLIT = false, bool SYM = false>
 struct StagedCfg {
-  using L = ChainLayout<N, M>;
+  using L = ChainLayout<N, M, SYM>;
+  static_assert(!SYM || (L::QLEN % 2 == 0 && L::RLEN % 2 == 0 && N % 2 == 0 && M % 2 == 0),
+                "the symmetric-packed kernels are instantiated where every block stays a whole number of 16-byte pieces");
   static constexpr int AB = N * N + N * M;                      // A | B
   static constexpr int STG = L::NODE + L::EDGE - (SPLIT ? AB : 0); // mats stage stride
   static constexpr int WSN = // S | g | h, even number of scalars
@@ -457,7 +465,7 @@ struct StagedCfg {
 // SPLIT (staged, mode 0 only): stage i's A | B of problem p are the N * (N + M) scalars at
 // ab + p * ab_pstride + i * ab_sstride (column-major A then B, as in the packed layout) and the
 // mats stage block is [Q | delta | M | R].
-template <int N, int M, bool STAGED, bool WPACK, bool SPLIT = false>
+template <int N, int M, bool STAGED, bool WPACK, bool SPLIT = false, bool SYM = false>
 __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     const double *__restrict__ mats, const double *__restrict__ vecs,
     double *__restrict__ sol, double *__restrict__ gains,
@@ -475,9 +483,10 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   constexpr bool VDIST = N == 16;
   static_assert(N >= 1 && N <= 16, "one problem per 16-lane row");
   static_assert(M >= 1 && M <= 16, "");
-  using L = ChainLayout<N, M>;
-  using C = StagedCfg<N, M, WPACK, SPLIT>;
+  using L = ChainLayout<N, M, SYM>;
+  using C = StagedCfg<N, M, WPACK, SPLIT, SYM>;
   static_assert(!SPLIT || (STAGED && WPACK), "the split kernel is the staged one");
+  static_assert(!SYM || (STAGED && !VDIST), "the symmetric-packed layout is served by the staged kernels");
   unsigned long long ts_begin = 0, ts_term = 0, ts_bwd = 0, ts_root = 0,
                      ts_end = 0, ts_a = 0, ts_b = 0, acc_bwait = 0,
                      acc_fwait = 0;
@@ -571,11 +580,24 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   // Loads [Q_i | q_i] as the augmented column.  nm / nv: stage block of mats /
   // vecs (global or LDS).
   auto load_vq = [&](auto nm, auto nv, double(&Vq)[N]) {
+    if constexpr (SYM) {
+      // column c of the symmetric Q out of its packed lower triangle: Q(r, c) = Q(max, min), packed column `min`
+      // starts at min N - min (min - 1) / 2 and holds rows min .. N - 1.  The vector lane reads q (offsets into nv).
+      const int base_c = cm * N - (cm * (cm - 1)) / 2 - cm; // + r for r >= c
+      sfor<0, N>([&](auto ii) {
+        constexpr int r = decltype(ii)::value;
+        constexpr int base_r = r * N - (r * (r - 1)) / 2 - r; // + c for c > r
+        const int off = r >= cm ? base_c + r : base_r + cm;
+        auto src = isV ? nv + r : nm + off; // one read per element: the address is selected, not the value
+        Vq[r] = *src;
+      });
+    } else {
     auto src = isV ? nv : nm + cm * N;
     sfor<0, N>([&](auto ii) {
       constexpr int r = decltype(ii)::value;
       Vq[r] = src[r];
     });
+    }
     if constexpr (VDIST)
       qd = nv[cm];
   };
@@ -590,11 +612,11 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     double cd; // VDIST: c_c of the node, one per lane
   };
   auto load_tail = [&](auto nm, auto nv, NodeTail &nt) {
-    const double d = nm[N * N + cm];
+    const double d = nm[L::QLEN + cm];
     nt.dl = isM ? d : 1.0;
     nt.cd = VDIST ? nv[N + cm] : 0.0;
     if constexpr (std::is_same_v<decltype(nm), lds_cdouble *>) {
-      auto csrc = isV ? nv + N : zeros, dsrc = isV ? nm + N * N : zeros;
+      auto csrc = isV ? nv + N : zeros, dsrc = isV ? nm + L::QLEN : zeros;
       sfor<0, N>([&](auto ii) {
         constexpr int r = decltype(ii)::value;
         nt.cv[r] = csrc[r];
@@ -604,7 +626,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       sfor<0, N>([&](auto ii) {
         constexpr int r = decltype(ii)::value;
         nt.cv[r] = isV ? nv[N + r] : 0.0;
-        nt.dv[r] = isV ? nm[N * N + r] : 0.0;
+        nt.dv[r] = isV ? nm[L::QLEN + r] : 0.0;
       });
     }
   };
@@ -696,6 +718,10 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
       auto msrc = isV ? nv + L::VNODE : nm + (OFF_M + cm);
       sfor<0, M>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
+        if constexpr (SYM) { // R(j, c) = R(max, min) of the packed lower triangle
+          const int lo = j < cu ? j : cu, hi = j < cu ? cu : j;
+          G[j] = nm[OFF_R + lo * M - (lo * (lo - 1)) / 2 + (hi - lo)];
+        } else
         G[j] = nm[OFF_R + cu * M + j]; // column c of R
         // column c of M^T = row c of M; vector lane: r
         H[j] = isV ? msrc[j] : msrc[j * N];
@@ -975,7 +1001,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     int woff[N];
     spill_row_offsets(woff);
     auto node_step = [&](const int i, const double v_) {
-      const double dl = pm[(long)i * STG + N * N + cm];
+      const double dl = pm[(long)i * STG + L::QLEN + cm];
       const double t_ = pv[(long)i * VSTG + N + cm] - dl * v_;
       const double sdi = rsqrt_nr(dl);
       const double phi = sdi * t_;
@@ -1069,7 +1095,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
     dma_fw.template issue<SIP_LQR_NT_FSP>((const char *)(wsp + p0 * ws_len + (long)(i + 1) * WSN),
                  buf + C::FA::BYTES + C::FG::BYTES, lane);
     dma_fd.template issue<SIP_LQR_NT_FAB>(
-        (const char *)(mats + p0 * mats_len + (long)(i + 1) * STG + N * N),
+        (const char *)(mats + p0 * mats_len + (long)(i + 1) * STG + L::QLEN),
         buf + C::FA::BYTES + C::FG::BYTES + C::FW::BYTES, lane);
   };
   if constexpr (STAGED) {
@@ -1085,7 +1111,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
   {
     const double gg = pw[WG + cm];
     const double hh = pw[WG + N + cm];
-    const double dd = pm[N * N + cm];
+    const double dd = pm[L::QLEN + cm];
     y = gg;
     x = (dd * rsqrt_nr(dd)) * hh;
     if (valid && isM) {
@@ -1143,7 +1169,7 @@ __global__ __launch_bounds__(64) void chain_factor_solve_qw16(
         issue_forward(i + 1, lds + (fbuf ^ 1) * C::F_BYTES);
     } else {
       read_stage(pm + (long)i * STG + L::NODE, pg + (long)i * L::GAIN,
-                 pw + (long)(i + 1) * WSN, pm + (long)(i + 1) * STG + N * N);
+                 pw + (long)(i + 1) * WSN, pm + (long)(i + 1) * STG + L::QLEN);
     }
 
     const double sdi = rsqrt_nr(dd), sdv = dd * sdi; // as node_factor computed them

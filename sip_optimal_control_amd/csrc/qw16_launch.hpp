@@ -36,6 +36,7 @@ struct KernelEntry {
   int ws_slot; // scalars of workspace per node
   launch_fs_t launch_fs;
   launch_mrhs_t launch_mrhs; // nullptr: this shape solves several right-hand sides column by column
+  int layout;                // SIP_LQR_LAYOUT_* of mats the kernel reads (0: the full squares)
 };
 
 template <int N, int M, bool WPACK>
@@ -51,10 +52,10 @@ hipError_t launch_mrhs_qw16(long batch, int T, const void *mats, const void *vec
   return hipGetLastError();
 }
 
-template <int N, int M, bool STAGED, bool WPACK>
+template <int N, int M, bool STAGED, bool WPACK, bool SYM = false>
 hipError_t launch_qw16(long batch, int T, const void *mats, const void *vecs, void *sol, void *gains,
                        int32_t *status, void *ws, hipStream_t stream, int mode, void *gfac) {
-  using Cfg = StagedCfg<N, M, WPACK>;
+  using Cfg = StagedCfg<N, M, WPACK, false, SYM>;
   const unsigned blocks = (unsigned)((batch + 3) / 4);
   const unsigned lds = STAGED ? Cfg::LDS_BYTES : 0;
   if (STAGED) {
@@ -63,7 +64,7 @@ hipError_t launch_qw16(long batch, int T, const void *mats, const void *vecs, vo
     if (bits & 15)
       return hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL((chain_factor_solve_qw16<N, M, STAGED, WPACK>), dim3(blocks), dim3(64), lds, stream,
+  hipLaunchKernelGGL((chain_factor_solve_qw16<N, M, STAGED, WPACK, false, SYM>), dim3(blocks), dim3(64), lds, stream,
                      (const double *)mats, (const double *)vecs, (double *)sol, (double *)gains, (double *)ws,
                      (int *)status, batch, T, mode, (double *)gfac, (const double *)nullptr, 0L, 0L SIP_STAMP_PASS);
   return hipGetLastError();
@@ -105,6 +106,11 @@ SIP_QW16_DECLARE_SLICE(4) SIP_QW16_DECLARE_SLICE(5) SIP_QW16_DECLARE_SLICE(6) SI
 
 } // namespace sipamd
 
+// symmetric-packed layout (SIP_LQR_LAYOUT_SYMMETRIC): Q and R as packed lower triangles; staged kernels, even n and m
+#define QW16_STAGED_SYM(N, M)                                                                                 \
+  { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",staged,sym>/f64",                               \
+    sipamd::StagedCfg<N, M, true, false, true>::WSN, &sipamd::launch_qw16<N, M, true, true, true>, nullptr,   \
+    SIP_LQR_LAYOUT_SYMMETRIC }
 // direct: every lane loads its columns from global memory (any N <= 16)
 #define QW16_DIRECT(N, M)                                                                                     \
   { SIP_LQR_F64, N, M, "chain_factor_solve_qw16<" #N "," #M ",direct>/f64",                                   \

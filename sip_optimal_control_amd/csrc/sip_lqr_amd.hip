@@ -21,6 +21,7 @@
 #include "stream_fill.hpp"
 
 struct sip_lqr_plan {
+  int layout = SIP_LQR_LAYOUT_FULL; // of mats
   int dtype;
   int64_t batch;
   int T, n, m, device;
@@ -96,6 +97,8 @@ const KernelEntry kKernels[] = {
     // (chain_mf32.hpp) stays selectable by SIP_LQR_VARIANT=mf32 for A/B timing
     MT16_ENTRY(SIP_LQR_F32, float, "f32", 8), MT16_ENTRY(SIP_LQR_F32, float, "f32", 4),
     MT16_ENTRY(SIP_LQR_F64, double, "f64", 8), MT16_ENTRY(SIP_LQR_F64, double, "f64", 4),
+    // symmetric-packed layout (sip_lqr_plan_create_layout): found only by plans that ask for it
+    QW16_STAGED_SYM(12, 4), QW16_STAGED_SYM(8, 4), QW16_STAGED_SYM(4, 4),
     MF32(8), QW16_STAGED_MR(12, 4), QW16_STAGED_MR(4, 2), QW16_DIRECT_MR(12, 4),
     QW16_DIRECT_MR(4, 2),  QW16_STAGED_MR(1, 1), QW16_STAGED_MR(2, 1),
     QW16_STAGED_MR(3, 2),  QW16_STAGED_MR(8, 3),
@@ -136,11 +139,11 @@ template <typename F> void for_each_kernel(F &&f) {
 #endif
 }
 
-const KernelEntry *find_kernel(int dtype, int n, int m) {
+const KernelEntry *find_kernel(int dtype, int n, int m, int layout = SIP_LQR_LAYOUT_FULL) {
   const char *want = std::getenv("SIP_LQR_VARIANT");
   const KernelEntry *found = nullptr;
   for_each_kernel([&](const KernelEntry &k) {
-    if (found == nullptr && k.dtype == dtype && k.n == n && k.m == m &&
+    if (found == nullptr && k.dtype == dtype && k.n == n && k.m == m && k.layout == layout &&
         (want == nullptr || want[0] == 0 || std::strstr(k.name, want)))
       found = &k;
   });
@@ -162,7 +165,7 @@ const KernelEntry *find_embedding_kernel(int n, int m) {
     return k.m < best->m;
   };
   for (const auto &k : kKernels)
-    if (k.dtype == SIP_LQR_F64 && k.n >= n && k.m >= m && better(k))
+    if (k.dtype == SIP_LQR_F64 && k.layout == SIP_LQR_LAYOUT_FULL && k.n >= n && k.m >= m && better(k))
       best = &k;
   return best;
 }
@@ -386,21 +389,32 @@ extern "C" {
 
 int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
                         int device, sip_lqr_plan **plan) {
+  return sip_lqr_plan_create_layout(dtype, batch, T, n, m, device, SIP_LQR_LAYOUT_FULL, plan);
+}
+
+int sip_lqr_plan_layout(const sip_lqr_plan *plan) { return plan ? plan->layout : SIP_LQR_LAYOUT_FULL; }
+
+int sip_lqr_plan_create_layout(int dtype, int64_t batch, int T, int n, int m, int device, int layout,
+                               sip_lqr_plan **plan) {
   if (plan == nullptr)
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   *plan = nullptr;
   if (batch < 1 || T < 0 || n < 1 || m < 1 ||
-      (dtype != SIP_LQR_F64 && dtype != SIP_LQR_F32))
+      (dtype != SIP_LQR_F64 && dtype != SIP_LQR_F32) ||
+      (layout != SIP_LQR_LAYOUT_FULL && layout != SIP_LQR_LAYOUT_SYMMETRIC))
     return SIP_LQR_ERR_INVALID_ARGUMENT;
   const char *want = std::getenv("SIP_LQR_VARIANT");
   const bool force_general = want != nullptr && std::strcmp(want, "general") == 0;
-  const KernelEntry *k = force_general ? nullptr : find_kernel(dtype, n, m);
+  const KernelEntry *k = force_general ? nullptr : find_kernel(dtype, n, m, layout);
+  if (layout != SIP_LQR_LAYOUT_FULL && k == nullptr)
+    return SIP_LQR_ERR_UNSUPPORTED; // only the dedicated kernels read the packed triangles
   if (k == nullptr && want != nullptr && want[0] != 0 && !force_general)
     return SIP_LQR_ERR_UNSUPPORTED; // an explicitly requested variant does not exist
   sip_lqr_plan *p = new (std::nothrow) sip_lqr_plan;
   if (p == nullptr)
     return SIP_LQR_ERR_ALLOC;
   p->dtype = dtype;
+  p->layout = layout;
   p->batch = batch;
   p->T = T;
   p->n = n;
@@ -425,7 +439,7 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
   p->launch_mrhs = (k != nullptr && !p->padded) ? k->launch_mrhs : nullptr;
   p->solve_only = k != nullptr && k->dtype == SIP_LQR_F64 && k->n <= 16; // qw16 only (mt16 re-runs the sweep)
   const char *split = std::getenv("SIP_LQR_SPLIT");
-  p->split_on_fused = p->launch_fs != nullptr && !(split && std::strcmp(split, "general") == 0);
+  p->split_on_fused = p->launch_fs != nullptr && (layout != SIP_LQR_LAYOUT_FULL || !(split && std::strcmp(split, "general") == 0));
   init_generic(p);
   // Device tables of the general engine: uploaded here, never lazily (include/sip_lqr_amd.h
   // promises that the compute entry points neither allocate nor synchronise).  A host without any
@@ -458,7 +472,9 @@ int64_t sip_lqr_plan_batch(const sip_lqr_plan *p) { return p ? p->batch : 0; }
 size_t sip_lqr_scalar_bytes(const sip_lqr_plan *p) { return p ? scalar_size(p) : 0; }
 size_t sip_lqr_mats_len(const sip_lqr_plan *p) {
   const size_t n = p->n, m = p->m, T = p->T;
-  return (T + 1) * (n * n + n) + T * (n * n + 2 * n * m + m * m);
+  const bool sym = p->layout == SIP_LQR_LAYOUT_SYMMETRIC;
+  const size_t qlen = sym ? n * (n + 1) / 2 : n * n, rlen = sym ? m * (m + 1) / 2 : m * m;
+  return (T + 1) * (qlen + n) + T * (n * n + 2 * n * m + rlen);
 }
 size_t sip_lqr_vecs_len(const sip_lqr_plan *p) {
   const size_t n = p->n, m = p->m, T = p->T;
@@ -505,8 +521,17 @@ void pack_one(const sip_lqr_plan *pl, int64_t p, double *const *Q,
       dst[i] = (S)src[i];
     dst += count;
   };
+  const bool sym = pl->layout == SIP_LQR_LAYOUT_SYMMETRIC;
+  auto put_lower = [](S *&dst, const double *src, int dim) { // lower triangle, packed by columns
+    for (int col = 0; col < dim; ++col)
+      for (int row = col; row < dim; ++row)
+        *dst++ = (S)src[row + dim * col];
+  };
   for (int i = 0; i <= T; ++i) {
-    put(mp, Q[i], n * n);
+    if (sym)
+      put_lower(mp, Q[i], n);
+    else
+      put(mp, Q[i], n * n);
     put(mp, delta[i], n);
     put(vp, q[i], n);
     put(vp, c[i], n);
@@ -514,7 +539,10 @@ void pack_one(const sip_lqr_plan *pl, int64_t p, double *const *Q,
       put(mp, A[i], n * n);
       put(mp, B[i], n * m);
       put(mp, M[i], n * m);
-      put(mp, R[i], m * m);
+      if (sym)
+        put_lower(mp, R[i], m);
+      else
+        put(mp, R[i], m * m);
       put(vp, r[i], m);
     }
   }
@@ -631,7 +659,7 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
 // The fused sweep with A | B read in place (chain_qw16.hpp, SPLIT; qw16_split.hip).
 int sip_lqr_has_split(const sip_lqr_plan *plan) {
   return plan != nullptr && plan->dtype == SIP_LQR_F64 && !plan->padded && plan->launch_fs != nullptr &&
-                 plan->kernel_name != nullptr &&
+                 plan->layout == SIP_LQR_LAYOUT_FULL && plan->kernel_name != nullptr &&
                  std::strstr(plan->kernel_name, "staged") != nullptr && sipamd::find_split_launch(plan->n, plan->m) != nullptr
              ? 1
              : 0;

@@ -11,15 +11,48 @@ class ChainShape:
     n: int
     m: int
     T: int
+    # SIP_LQR_LAYOUT_SYMMETRIC: Q and R as lower triangles packed by columns (include/sip_lqr_amd.h)
+    symmetric: bool = False
+
+    @property
+    def qlen(self):
+        return self.n * (self.n + 1) // 2 if self.symmetric else self.n * self.n
+
+    @property
+    def rlen(self):
+        return self.m * (self.m + 1) // 2 if self.symmetric else self.m * self.m
 
     # scalars per stage block
     @property
     def node(self):  # Q | delta
-        return self.n * self.n + self.n
+        return self.qlen + self.n
 
     @property
     def edge(self):  # A | B | M | R
-        return self.n * self.n + 2 * self.n * self.m + self.m * self.m
+        return self.n * self.n + 2 * self.n * self.m + self.rlen
+
+    def full(self):
+        return ChainShape(self.n, self.m, self.T)
+
+    def packed(self):
+        return ChainShape(self.n, self.m, self.T, symmetric=True)
+
+    def pack_index(self):
+        """Index array (numpy int64): mats of the FULL layout [.., full.mats_len] -> mats of this (symmetric)
+        layout, `sym = full[..., index]`."""
+        import numpy as np
+        f = self.full()
+        assert self.symmetric
+        n, m = self.n, self.m
+        tri_n = [r + n * c for c in range(n) for r in range(c, n)]
+        tri_m = [r + m * c for c in range(m) for r in range(c, m)]
+        idx = []
+        for i in range(self.T + 1):
+            o = f.mats_off(i)
+            idx += [o["Q"] + k for k in tri_n] + [o["delta"] + k for k in range(n)]
+            if i < self.T:
+                idx += list(range(o["A"], o["R"])) + [o["R"] + k for k in tri_m]
+        return np.asarray(idx, dtype=np.int64)
 
     @property
     def vnode(self):  # q | c   (x | y in sol)
@@ -49,7 +82,7 @@ class ChainShape:
     def mats_off(self, i):
         base = i * (self.node + self.edge)
         n, m = self.n, self.m
-        off = {"Q": base, "delta": base + n * n}
+        off = {"Q": base, "delta": base + self.qlen}
         e = base + self.node
         off.update({"A": e, "B": e + n * n, "M": e + n * n + n * m, "R": e + n * n + 2 * n * m})
         return off
