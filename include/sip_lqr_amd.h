@@ -116,9 +116,10 @@ int sip_lqr_plan_create(int dtype, int64_t batch, int T, int n, int m,
 /* The same with a layout of `mats` other than FULL.  SIP_LQR_LAYOUT_SYMMETRIC: fp64 shapes with a symmetric-packed
  * fused kernel (sip_lqr_kernel_name() carries "sym": LDS-staged kernels with even n and m whose blocks stay whole
  * 16-byte pieces, the reference's n = 12, m = 4 benchmark shape among them); SIP_LQR_ERR_UNSUPPORTED otherwise.
- * sip_lqr_mats_len / _bytes, sip_lqr_pack_problem and every compute entry point follow the plan's layout;
- * sip_lqr_factor_solve_split and the one-sweep sip_lqr_solve_multi are FULL-layout only (solve_multi then goes
- * column by column). */
+ * sip_lqr_mats_len / _bytes, sip_lqr_split_mats_len, sip_lqr_pack_problem and every compute entry point follow the
+ * plan's layout (sip_lqr_factor_solve_split: [Q | delta | M | R] with Q, R packed; what the Newton-KKT step's
+ * condensation then writes); the one-sweep sip_lqr_solve_multi is FULL-layout only (a SYMMETRIC plan goes column by
+ * column). */
 int sip_lqr_plan_create_layout(int dtype, int64_t batch, int T, int n, int m, int device, int layout,
                                sip_lqr_plan **plan);
 int sip_lqr_plan_layout(const sip_lqr_plan *plan);

@@ -35,6 +35,9 @@ struct ChainKkt {
   // 1: the Riccati sweep reads ddyn_dx | ddyn_du in place (sip_lqr_factor_solve_split): the stage
   // blocks of mats are [Q_mod | dyn_r2 | M_mod | R_mod] and nothing copies A | B (helpers.cpp:365-366)
   int split;
+  // 1 (with split): Q_mod and R_mod leave as packed lower triangles (SIP_LQR_LAYOUT_SYMMETRIC): the tiles below
+  // compute the lower triangle anyway -- no mirror writes, a third less of mats written here and read by the sweep
+  int sym;
 };
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -293,7 +296,9 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
     const int li = tid & 15, lg = tid >> 4;
     const int ncols = last ? n : n + m;
     const int nt = (ncols + 15) >> 4;
-    double *Qm = mats, *Am = mats + nn + n, *Bm = Am + nn, *Mm = ck.split ? Am : Bm + nm, *Rm = Mm + nm;
+    const bool sym = ck.sym != 0; // (only with split)
+    const int qlen = sym ? n * (n + 1) / 2 : nn;
+    double *Qm = mats, *Am = mats + qlen + n, *Bm = Am + nn, *Mm = ck.split ? Am : Bm + nm, *Rm = Mm + nm;
     for (int ti = 0; ti < nt; ++ti) {
       for (int tj = 0; tj <= ti; ++tj) {
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -323,8 +328,12 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
               if (!last)
                 v += eb[I + n * J];
               v += t;
-              Qm[I + n * J] = v;
-              Qm[J + n * I] = v;
+              if (sym) {
+                Qm[J * n - (J * (J - 1)) / 2 + (I - J)] = v; // packed column J, rows J .. n-1
+              } else {
+                Qm[I + n * J] = v;
+                Qm[J + n * I] = v;
+              }
             }
           } else if (I < ncols) {
             const int u = I - n;
@@ -336,15 +345,19 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
               if (u == uj)
                 v += r1s[n + u];
               v += t;
-              Rm[u + m * uj] = v;
-              Rm[uj + m * u] = v;
+              if (sym) {
+                Rm[uj * m - (uj * (uj - 1)) / 2 + (u - uj)] = v;
+              } else {
+                Rm[u + m * uj] = v;
+                Rm[uj + m * u] = v;
+              }
             }
           }
         }
       }
     }
     if (tid < n)
-      mats[nn + tid] = pre.d; // dyn_r2
+      mats[(ck.sym ? n * (n + 1) / 2 : nn) + tid] = pre.d; // dyn_r2
     if (!last && !ck.split) {
       for (int k = tid; k < nn; k += TPB) // ddyn_dx, ddyn_du, :365-366
         Am[k] = eb[o_a + k];
@@ -354,7 +367,7 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
   }
   if (MATS) {
     __syncthreads();
-    const int len = last ? nn + n : ck.mats_stage;
+    const int len = last ? (ck.sym ? n * (n + 1) / 2 : nn) + n : ck.mats_stage;
     for (int k = tid; k < len; k += TPB)
       it.mats[k] = obuf[k];
   }

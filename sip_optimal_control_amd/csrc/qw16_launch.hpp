@@ -76,25 +76,25 @@ hipError_t launch_qw16(long batch, int T, const void *mats, const void *vecs, vo
 typedef hipError_t (*launch_split_t)(long batch, int T, const void *mats, const void *ab, long ab_pstride,
                                      long ab_sstride, const void *vecs, void *sol, void *gains, int32_t *status,
                                      void *ws, hipStream_t stream);
-template <int N, int M>
+template <int N, int M, bool SYM = false>
 hipError_t launch_qw16_split(long batch, int T, const void *mats, const void *ab, long ab_pstride, long ab_sstride,
                              const void *vecs, void *sol, void *gains, int32_t *status, void *ws,
                              hipStream_t stream) {
-  using Cfg = StagedCfg<N, M, true, true>;
+  using Cfg = StagedCfg<N, M, true, true, SYM>;
   // 16-byte pieces: bases and strides (the LDS-DMA itself is exact from 8-byte-aligned sources on
   // gfx950, tools/ubench/lds_dma_align.hip, but the per-problem / per-stage strides must keep the pieces whole)
   const uintptr_t bits = (uintptr_t)mats | (uintptr_t)vecs | (uintptr_t)gains | (uintptr_t)ws | (uintptr_t)ab |
                          (uintptr_t)(ab_pstride * 8) | (uintptr_t)(ab_sstride * 8);
   if (bits & 15)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL((chain_factor_solve_qw16<N, M, true, true, true>), dim3((unsigned)((batch + 3) / 4)), dim3(64),
+  hipLaunchKernelGGL((chain_factor_solve_qw16<N, M, true, true, true, SYM>), dim3((unsigned)((batch + 3) / 4)), dim3(64),
                      Cfg::LDS_BYTES, stream, (const double *)mats, (const double *)vecs, (double *)sol,
                      (double *)gains, (double *)ws, (int *)status, batch, T, 0, (double *)nullptr,
                      (const double *)ab, ab_pstride, ab_sstride SIP_STAMP_PASS);
   return hipGetLastError();
 }
-launch_split_t find_split_launch(int n, int m);             // qw16_split.hip; nullptr: no split kernel for the shape
-long split_mats_stage(int n, int m);                        // scalars of [Q | delta | M | R]
+launch_split_t find_split_launch(int n, int m, int layout = 0); // qw16_split.hip; nullptr: no split kernel for the shape / layout
+long split_mats_stage(int n, int m, int layout = 0);            // scalars of [Q | delta | M | R]
 
 // The shapes n <= 16, m <= 8 that sip_lqr_amd.hip does not instantiate itself live in eight slices
 // of qw16_extra.hip (compiled in parallel): slice s defines qw16_extra_slice_<s>.

@@ -14,12 +14,14 @@ namespace sipamd {
 struct SplitEntry {
   int n, m;
   launch_split_t launch;
+  int layout; // SIP_LQR_LAYOUT_* of the [Q | delta | M | R] blocks
 };
 const SplitEntry *qw16_split_slice_1(int *count);
 const SplitEntry *qw16_split_slice_2(int *count);
 const SplitEntry *qw16_split_slice_3(int *count);
 
-#define QW16_SPLIT(N, M) {N, M, &launch_qw16_split<N, M>}
+#define QW16_SPLIT(N, M) {N, M, &launch_qw16_split<N, M>, SIP_LQR_LAYOUT_FULL}
+#define QW16_SPLIT_SYM(N, M) {N, M, &launch_qw16_split<N, M, true>, SIP_LQR_LAYOUT_SYMMETRIC}
 // the staged shapes of the reference's Newton-KKT benchmark grid (newton_kkt_benchmark.cpp:264-273:
 // n in {4, 6, 8}, m in {1, 2, 3, 4}) and n = 12 (the f1 shape of bench.py and its fewer-control relatives)
 #if SIP_QW16_SPLIT_SLICE == 0
@@ -28,9 +30,9 @@ namespace {
 const SplitEntry kSplit[] = {QW16_SPLIT(12, 4), QW16_SPLIT(4, 2), QW16_SPLIT(4, 4), QW16_SPLIT(6, 2)};
 }
 
-launch_split_t find_split_launch(int n, int m) {
+launch_split_t find_split_launch(int n, int m, int layout) {
   for (const SplitEntry &e : kSplit)
-    if (e.n == n && e.m == m)
+    if (e.n == n && e.m == m && e.layout == layout)
       return e.launch;
 #if !defined(SIP_QW16_QUICK) && !defined(SIP_QW16_NO_EXTRA) // tools/ab_build.sh, tools/diag_build.sh link slice 0 alone
   typedef const SplitEntry *(*slice_fn)(int *);
@@ -38,14 +40,17 @@ launch_split_t find_split_launch(int n, int m) {
     int count = 0;
     const SplitEntry *more = fn(&count);
     for (int k = 0; k < count; ++k)
-      if (more[k].n == n && more[k].m == m)
+      if (more[k].n == n && more[k].m == m && more[k].layout == layout)
         return more[k].launch;
   }
 #endif
   return nullptr;
 }
 
-long split_mats_stage(int n, int m) { return (long)n * n + n + (long)n * m + (long)m * m; }
+long split_mats_stage(int n, int m, int layout) {
+  const bool sym = layout == SIP_LQR_LAYOUT_SYMMETRIC;
+  return (sym ? (long)n * (n + 1) / 2 : (long)n * n) + n + (long)n * m + (sym ? (long)m * (m + 1) / 2 : (long)m * m);
+}
 
 #else
 
@@ -53,9 +58,10 @@ namespace {
 #if SIP_QW16_SPLIT_SLICE == 1
 const SplitEntry kSplit[] = {QW16_SPLIT(6, 4), QW16_SPLIT(8, 2), QW16_SPLIT(8, 4), QW16_SPLIT(12, 2)};
 #elif SIP_QW16_SPLIT_SLICE == 2
-const SplitEntry kSplit[] = {QW16_SPLIT(12, 3), QW16_SPLIT(4, 1), QW16_SPLIT(4, 3), QW16_SPLIT(6, 1)};
+const SplitEntry kSplit[] = {QW16_SPLIT(12, 3), QW16_SPLIT(4, 1), QW16_SPLIT(4, 3), QW16_SPLIT(6, 1), QW16_SPLIT_SYM(12, 4)};
 #else
-const SplitEntry kSplit[] = {QW16_SPLIT(12, 1), QW16_SPLIT(6, 3), QW16_SPLIT(8, 1), QW16_SPLIT(8, 3)};
+const SplitEntry kSplit[] = {QW16_SPLIT(12, 1), QW16_SPLIT(6, 3), QW16_SPLIT(8, 1), QW16_SPLIT(8, 3), QW16_SPLIT_SYM(8, 4),
+                             QW16_SPLIT_SYM(4, 4)};
 #endif
 } // namespace
 

@@ -41,6 +41,9 @@ struct sip_kkt_plan {
   // the fused step hands the Riccati sweep ddyn_dx | ddyn_du in the model arena instead of copying
   // them into its inputs (sip_lqr_factor_solve_split); SIP_KKT_SPLIT=0 keeps the copy
   bool chain_split = false;
+  // ... and with Q_mod / R_mod as packed lower triangles (SIP_LQR_LAYOUT_SYMMETRIC) where the sweep has that kernel:
+  // a second plan of the same shape, used by the fused step only; SIP_KKT_SYM=0 keeps the full squares
+  sip_lqr_plan *chain_sym = nullptr;
   int chain_pipe = 0;         // > 0: stages per wavefront of the software-pipelined condensation
   sipamd::kkt::ChainKkt ck{};
   size_t lds_chain_condense = 0, lds_chain_recover = 0, lds_chain_apply = 0;
@@ -57,6 +60,8 @@ struct sip_kkt_plan {
   ~sip_kkt_plan() {
     if (chain)
       sip_lqr_plan_destroy(chain);
+    if (chain_sym)
+      sip_lqr_plan_destroy(chain_sym);
     if (tree)
       sip_lqr_tree_plan_destroy(tree);
     if (d_ints)
@@ -149,13 +154,14 @@ int even(int v) { return (v + 1) / 2 * 2; }
 // split (chain kernels only): mats for sip_lqr_factor_solve_split -- no A | B in it.
 hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double *model, const double *w,
                            const double *r1, const double *r2, const double *r3, const double *b,
-                           hipStream_t s, const bool split = false) {
+                           hipStream_t s, const bool split = false, const bool sym = false) {
   sipamd::kkt::ChainKkt ck = p->ck;
   if (split) {
     const int n = ck.n, m = ck.m;
-    ck.split = 1;
-    ck.mats_stage = (n * n + n) + (n * m + m * m);
-    ck.mats_len = (long)(ck.T + 1) * (n * n + n) + (long)ck.T * (n * m + m * m);
+    const int qlen = sym ? n * (n + 1) / 2 : n * n, rlen = sym ? m * (m + 1) / 2 : m * m;
+    ck.split = 1, ck.sym = sym ? 1 : 0;
+    ck.mats_stage = (qlen + n) + (n * m + rlen);
+    ck.mats_len = (long)(ck.T + 1) * (qlen + n) + (long)ck.T * (n * m + rlen);
   }
   hipError_t e = sipamd::zero_async(r.reg, (size_t)p->batch * sizeof(int), s); // a kernel: stream_fill.hpp
   if (e != hipSuccess)
@@ -473,7 +479,7 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
     ck.model_len = p->model_len, ck.x_dim = p->x_dim, ck.y_dim = p->y_dim, ck.z_dim = p->z_dim;
     ck.mats_stage = (n * n + n) + (n * n + 2 * n * mm + mm * mm), ck.vecs_stage = 2 * n + mm;
     ck.mats_len = p->in0_len, ck.vecs_len = p->in1_len;
-    ck.split = 0;
+    ck.split = 0, ck.sym = 0;
     const int cgn = std::max(ck.cn + ck.gn, ck.cT + ck.gT), cge = ck.ce + ck.ge;
     ck.lds_item = even(n * n + cgn * n + ck.edge_len);
     ck.lds_tail = even(cgn * n + cge * (n + mm)); // recover: every Jacobian of a stage
@@ -500,10 +506,20 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
     p->chain_pipe = fits && per > 0 ? per : 0;
     const char *se = std::getenv("SIP_KKT_SPLIT");
     p->chain_split = E > 0 && sip_lqr_has_split(p->chain) == 1 && !(se != nullptr && se[0] == '0');
+    const char *sy = std::getenv("SIP_KKT_SYM");
+    if (p->chain_split && !(sy != nullptr && sy[0] == '0')) {
+      if (sip_lqr_plan_create_layout(SIP_LQR_F64, batch, E, p->sd[0], p->cd[0], device, SIP_LQR_LAYOUT_SYMMETRIC,
+                                     &p->chain_sym) != SIP_LQR_OK ||
+          sip_lqr_has_split(p->chain_sym) != 1 ||
+          sip_lqr_workspace_bytes(p->chain_sym) > sip_lqr_workspace_bytes(p->chain)) { // (shares the sweep's scratch)
+        sip_lqr_plan_destroy(p->chain_sym);
+        p->chain_sym = nullptr;
+      }
+    }
   }
   p->name += p->chain_kernels ? " + chain condensation" : p->staged ? " + staged condensation" : " + direct condensation";
   if (p->chain_split)
-    p->name += " (A|B in place)";
+    p->name += p->chain_sym != nullptr ? " (A|B in place, Q|R packed)" : " (A|B in place)";
 
   std::vector<int> ints;
   auto pi = [&](const std::vector<int> &v) {
@@ -678,13 +694,14 @@ int sip_kkt_factor_solve(const sip_kkt_plan *p, const double *d_model, const dou
   const long ab_stage = (long)p->ck.node_len + p->ck.edge_len;
   const bool split = p->chain_split && fused_rhs && p->E > 0 &&
                      ((((uintptr_t)d_model >> 3) | (uintptr_t)ab_off | (uintptr_t)ab_stage | (uintptr_t)p->ck.model_len) & 1) == 0;
-  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, fused_rhs ? d_b : nullptr, s, split);
+  const bool sym = split && p->chain_sym != nullptr;
+  hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, fused_rhs ? d_b : nullptr, s, split, sym);
   if (e == hipSuccess && !fused_rhs)
     e = launch_rhs(p, r, d_model, d_b, nullptr, s);
   if (e != hipSuccess)
     return report(e, "sip_kkt_factor_solve(condense)");
-  const int rc = split ? sip_lqr_factor_solve_split(p->chain, r.in0, d_model + ab_off, p->ck.model_len, ab_stage, r.in1,
-                                                    r.out, r.gain, d_status, r.lqr, s)
+  const int rc = split ? sip_lqr_factor_solve_split(sym ? p->chain_sym : p->chain, r.in0, d_model + ab_off,
+                                                    p->ck.model_len, ab_stage, r.in1, r.out, r.gain, d_status, r.lqr, s)
                        : sip_lqr_factor_solve(p->chain, r.in0, r.in1, r.out, r.gain, d_status, r.lqr, s);
   if (rc != SIP_LQR_OK)
     return rc;

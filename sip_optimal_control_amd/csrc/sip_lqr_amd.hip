@@ -659,8 +659,8 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
 // The fused sweep with A | B read in place (chain_qw16.hpp, SPLIT; qw16_split.hip).
 int sip_lqr_has_split(const sip_lqr_plan *plan) {
   return plan != nullptr && plan->dtype == SIP_LQR_F64 && !plan->padded && plan->launch_fs != nullptr &&
-                 plan->layout == SIP_LQR_LAYOUT_FULL && plan->kernel_name != nullptr &&
-                 std::strstr(plan->kernel_name, "staged") != nullptr && sipamd::find_split_launch(plan->n, plan->m) != nullptr
+                 plan->kernel_name != nullptr && std::strstr(plan->kernel_name, "staged") != nullptr &&
+                 sipamd::find_split_launch(plan->n, plan->m, plan->layout) != nullptr
              ? 1
              : 0;
 }
@@ -668,8 +668,10 @@ int sip_lqr_has_split(const sip_lqr_plan *plan) {
 int64_t sip_lqr_split_mats_len(const sip_lqr_plan *plan) {
   if (plan == nullptr)
     return 0;
-  const long node = (long)plan->n * plan->n + plan->n;
-  return (int64_t)(plan->T + 1) * node + (int64_t)plan->T * (sipamd::split_mats_stage(plan->n, plan->m) - node);
+  const bool sym = plan->layout == SIP_LQR_LAYOUT_SYMMETRIC;
+  const long node = (sym ? (long)plan->n * (plan->n + 1) / 2 : (long)plan->n * plan->n) + plan->n;
+  return (int64_t)(plan->T + 1) * node +
+         (int64_t)plan->T * (sipamd::split_mats_stage(plan->n, plan->m, plan->layout) - node);
 }
 
 int sip_lqr_factor_solve_split(const sip_lqr_plan *plan, const void *d_mats, const void *d_ab,
@@ -690,7 +692,7 @@ int sip_lqr_factor_solve_split(const sip_lqr_plan *plan, const void *d_mats, con
   sipamd::DeviceGuard on_device(plan->device);
   if (on_device.err != hipSuccess)
     return report(on_device.err, "sip_lqr_factor_solve_split(hipSetDevice)");
-  const sipamd::launch_split_t launch = sipamd::find_split_launch(plan->n, plan->m);
+  const sipamd::launch_split_t launch = sipamd::find_split_launch(plan->n, plan->m, plan->layout);
   return report(launch(plan->batch, plan->T, d_mats, d_ab, (long)ab_problem_stride, (long)ab_stage_stride, d_vecs,
                        d_sol, d_gains, d_status, d_workspace, (hipStream_t)stream),
                 "sip_lqr_factor_solve_split");

@@ -191,6 +191,32 @@ def test_null_constraint_dims_and_single_node():
     np.testing.assert_allclose(sol1.cpu().numpy()[0], np.linalg.solve(K, rhs1), rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,m,T", [(12, 4, 9), (8, 4, 6), (4, 4, 5)])
+def test_packed_condensation_gives_the_same_bits(monkeypatch, n, m, T):
+    """Where the sweep has the symmetric-packed split kernel, the fused step's condensation writes Q_mod and R_mod as
+    packed lower triangles (it computes only the lower tiles anyway; helpers.cpp:155-158, 353-360 mirror them) and
+    the sweep reads them with SIP_LQR_LAYOUT_SYMMETRIC: the same arithmetic on the same numbers as the full squares
+    (SIP_KKT_SYM=0), so the same bits -- and, as every path, the oracle's solution to 1e-9."""
+    dims = rk.newton_kkt_dims(n, m, T)
+    batch = 7
+    arrays = rk.newton_kkt_problem(dims, seed=33, batch=batch, r2_max=1e2)
+    d = _dev(*arrays)
+    packed = _make(dims, batch)
+    assert "(A|B in place, Q|R packed)" in packed.kernel_name
+    sol_p, st_p = packed.factor_solve(*d)
+    sol_p = sol_p.clone()
+    monkeypatch.setenv("SIP_KKT_SYM", "0")
+    full = _make(dims, batch)
+    assert "(A|B in place)" in full.kernel_name and "packed" not in full.kernel_name
+    sol_f, st_f = full.factor_solve(*d)
+    torch.cuda.synchronize()
+    assert st_p.cpu().tolist() == [0] * batch == st_f.cpu().tolist()
+    assert torch.equal(sol_p, sol_f)
+    ref, ref_status = KKTOracle(dims).batch(*arrays, threads=4)
+    assert (ref_status == 0).all()
+    assert float(np.abs(sol_p.cpu().numpy() - ref).max() / np.abs(ref).max()) <= 1e-9
+
+
 def test_condensation_variants_agree_bitwise(monkeypatch):
     """The table-driven LDS-staged kernels and the direct kernels (fallback for items too large for
     LDS) accumulate every element in the same order with the same operations; the uniform-chain

@@ -79,5 +79,5 @@ def test_unsupported_shapes_and_host_side_packing(oracle_lib):
     with pytest.raises(LQRLibraryError):
         BatchedChainLQR(32, 8, 4, 2, dtype=torch.float32, symmetric=True)
     s = BatchedChainLQR(12, 4, 3, 2, symmetric=True)
-    assert s._lib.sip_lqr_plan_layout(s._plan) == 1 and not s.has_split
+    assert s._lib.sip_lqr_plan_layout(s._plan) == 1 and s.has_split  # (the Newton-KKT step's sweep: packed [Q | delta | M | R])
     assert s.solve_multi_workspace_bytes(4) == 0                # several right-hand sides: column by column
