@@ -16,7 +16,9 @@ hipError_t launch(const TreeSchedule &ts, const double *input, double *output, d
 }
 #define TREE_CLASS(N, M) {N, M, "tree_factor_solve_qw16<" #N "," #M ">/f64", &launch<N, M, false>, &launch<N, M, true>}
 // sorted by cost: the first class that holds the largest node and the largest control wins
-const TreeClass kClasses[] = {TREE_CLASS(4, 2),  TREE_CLASS(6, 3),  TREE_CLASS(8, 4),  TREE_CLASS(10, 4),
+// ((9, 3): the reference's variable-shape benchmark family at base dimension 8 -- states 7..9, controls 1..3,
+// benchmarks/lqr_benchmark.cpp:209-310 -- padded to (10, 4) before round 3)
+const TreeClass kClasses[] = {TREE_CLASS(4, 2),  TREE_CLASS(6, 3),  TREE_CLASS(8, 4),  TREE_CLASS(9, 3), TREE_CLASS(10, 4),
                               TREE_CLASS(12, 4), TREE_CLASS(15, 4), TREE_CLASS(15, 8)};
 #undef TREE_CLASS
 } // namespace
