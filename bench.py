@@ -192,18 +192,23 @@ def kkt_main(args):
     for _ in range(args.warmup):
         kkt.factor_solve(*data, sol=sol)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        kkt.factor_solve(*data, sol=sol)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    block_s = []  # `blocks` timed blocks of exactly `steps` steps; the line reports the median block
+    for _ in range(max(1, args.blocks)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            kkt.factor_solve(*data, sol=sol)
+        torch.cuda.synchronize()
+        block_s.append(time.perf_counter() - t0)
+    elapsed = sorted(block_s)[len(block_s) // 2]
     ms = elapsed / args.steps * 1e3
     alg_bytes = 8 * (kkt.model_len + 2 * kkt.z_dim + kkt.x_dim + kkt.y_dim + 2 * kkt.kkt_dim)
     achieved = batch * alg_bytes / (ms * 1e-3) / 1e9
     kkt_traffic, kkt_traffic_src = recorded_traffic(f"kkt:{kkt.kernel_name}") if batch == 4096 else (None, None)
     out = {
         "metric": "Newton-KKT factor+solves/sec", "value": batch * args.steps / elapsed, "unit": "solves/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "blocks": max(1, args.blocks),
+        "ms_per_step_min": min(block_s) / args.steps * 1e3, "ms_per_step_max": max(block_s) / args.steps * 1e3,
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"kkt: NewtonKKTProblem(n={n}, m={m}, T={T}), c={c}, g={g}, batch {batch}",
                    "kernels": kkt.kernel_name, "all_status_success": bool((kkt.status == 0).all().item())},
