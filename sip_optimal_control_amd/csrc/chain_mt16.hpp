@@ -63,6 +63,7 @@ template <typename S> struct Tr;
 template <> struct Tr<float> {
   typedef float v4 __attribute__((ext_vector_type(4)));
   static constexpr bool ROWS_CONTIGUOUS = true; // registers 0..3 of a lane are consecutive rows
+  static constexpr int RSTEP = 1;                // row(g, v) = row(g, 0) + RSTEP * v
   static __device__ __forceinline__ constexpr int row(const int g, const int v) { return 4 * g + v; }
   static __device__ __forceinline__ v4 mfma(const float a, const float b, const v4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -80,6 +81,7 @@ template <> struct Tr<float> {
 template <> struct Tr<double> {
   typedef double v4 __attribute__((ext_vector_type(4)));
   static constexpr bool ROWS_CONTIGUOUS = false;
+  static constexpr int RSTEP = 4;
   static __device__ __forceinline__ constexpr int row(const int g, const int v) { return g + 4 * v; }
   static __device__ __forceinline__ v4 mfma(const double a, const double b, const v4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -105,6 +107,51 @@ __device__ __forceinline__ double fma_(const double a, const double b, const dou
 // outstanding load, spill store and gains store -- six times per stage; this only keeps the compiler from moving
 // memory operations across the point (no instruction is emitted).
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_wave_barrier(); }
+
+// Global memory through buffer instructions: SGPR descriptor (one per array, based at the wavefront's problem), one
+// 32-bit VGPR byte offset per lane pattern, an SGPR offset for the stage and a 12-bit immediate -- no 64-bit pointer
+// pair per access in the VGPRs.  Offsets in BYTES.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, const long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+template <typename S> struct Mem;
+template <> struct Mem<float> {
+  typedef Tr<float>::v4 v4;
+  static __device__ __forceinline__ float ld(const rsrc_t r, const unsigned vo, const unsigned so) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+  }
+  static __device__ __forceinline__ v4 ld4(const rsrc_t r, const unsigned vo, const unsigned so) {
+    return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+  }
+  static __device__ __forceinline__ void st(const float x, const rsrc_t r, const unsigned vo, const unsigned so) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, vo, so, 0);
+  }
+  static __device__ __forceinline__ void st4(const v4 x, const rsrc_t r, const unsigned vo, const unsigned so) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), r, vo, so, 0);
+  }
+};
+template <> struct Mem<double> {
+  typedef Tr<double>::v4 v4;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ double ld(const rsrc_t r, const unsigned vo, const unsigned so) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));
+  }
+  static __device__ __forceinline__ v4 ld4(const rsrc_t r, const unsigned vo, const unsigned so) {
+    const d2 a = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+    const d2 b = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, vo + 16u, so, 0));
+    return v4{a[0], a[1], b[0], b[1]};
+  }
+  static __device__ __forceinline__ void st(const double x, const rsrc_t r, const unsigned vo, const unsigned so) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, x), r, vo, so, 0);
+  }
+  static __device__ __forceinline__ void st4(const v4 x, const rsrc_t r, const unsigned vo, const unsigned so) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d2{x[0], x[1]}), r, vo, so, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d2{x[2], x[3]}), r, vo + 16u, so, 0);
+  }
+};
 
 template <typename S> struct Mat32 { // 32 x 32: t[I][J]
   typename Tr<S>::v4 t[2][2];
@@ -133,11 +180,31 @@ __device__ __forceinline__ void mul_tt(const Mat32<S> &U, const Mat32<S> &V, Mat
 }
 
 // Position of the lane and the control index of a tile row / column.
+// Lane selectors of the sweep.  fp64: one-hot vectors in registers (the selection is a handful of FMAs).  fp32,
+// where the register budget decides the occupancy: lane MASKS in SGPR pairs, applied by v_cndmask.
+typedef unsigned long long lanemask_t;
 template <typename S> struct LaneT {
   int lane, j, g;
   S eg[4]; // one-hot of the lane group:      eg[k] = (g == k)
   S ej[4]; // one-hot of the tile rows row(kk, 0): ej[kk] = (j == row(kk, 0))
 };
+template <> struct LaneT<float> {
+  int lane, j, g;
+  lanemask_t mg[4], mj[4]; // lanes with g == k / with j == row(kk, 0)
+};
+// mask[lane] ? a : b.  The masks are laundered through an empty asm when they are built (so that the compiler cannot
+// fold them back into comparisons of the lane group, which it then lowers to exec-masked branches -- a switch -- when
+// selects on the same value nest); the selects themselves are the compiler's own v_cndmask with an SGPR-pair mask,
+// so every hazard around them (transcendental results, MFMA operands) is its business, not an inline asm's.
+__device__ __forceinline__ float sel(const lanemask_t m, const float a, const float b) {
+  return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b;
+}
+__device__ __forceinline__ lanemask_t opaque_mask(const bool lane_predicate) {
+  lanemask_t m = __builtin_amdgcn_ballot_w64(lane_predicate);
+  asm volatile("" : "+s"(m));
+  return m;
+}
+
 // control index of tile row row(g, v): a = g + 4 v
 __device__ __forceinline__ constexpr int ctrl_of(const int g, const int v) { return g + 4 * v; }
 // control index of tile COLUMN j (the (g', v') with row(g', v') == j)
@@ -248,11 +315,21 @@ __device__ __forceinline__ bool sweep(typename Tr<S>::v4 (&T)[TILES][TILES], con
       const S m20 = fma_(l21, l10, -l20);
       const S m31 = fma_(l32, l21, -l31);
       const S m30 = fma_(-l32, m20, fma_(l31, l10, -l30));
-      const S t1 = fma_(m10, L.eg[0], L.eg[1]);
-      const S t2 = fma_(m20, L.eg[0], fma_(m21, L.eg[1], L.eg[2]));
-      const S t3 = fma_(m30, L.eg[0], fma_(m31, L.eg[1], fma_(m32, L.eg[2], L.eg[3])));
-      const S amix = fma_(L.ej[0], L.eg[0], fma_(L.ej[1], t1, fma_(L.ej[2], t2, L.ej[3] * t3)));
-      const S ig = fma_(i0, L.eg[0], fma_(i1, L.eg[1], fma_(i2, L.eg[2], i3 * L.eg[3]))); // 1 / d_g
+      S amix, ig;
+      if constexpr (sizeof(S) == 4) { // column g of M = (M e_g): selected by the lane-group masks
+        const S e1 = sel(L.mg[1], S(1), S(0)), e2 = sel(L.mg[2], S(1), S(0)), e3 = sel(L.mg[3], S(1), S(0));
+        const S t1 = sel(L.mg[0], m10, e1);
+        const S t2 = sel(L.mg[0], m20, sel(L.mg[1], m21, e2));
+        const S t3 = sel(L.mg[0], m30, sel(L.mg[1], m31, sel(L.mg[2], m32, e3)));
+        amix = sel(L.mj[0], sel(L.mg[0], S(1), S(0)), sel(L.mj[1], t1, sel(L.mj[2], t2, sel(L.mj[3], t3, S(0)))));
+        ig = sel(L.mg[0], i0, sel(L.mg[1], i1, sel(L.mg[2], i2, i3))); // 1 / d_g
+      } else {
+        const S t1 = fma_(m10, L.eg[0], L.eg[1]);
+        const S t2 = fma_(m20, L.eg[0], fma_(m21, L.eg[1], L.eg[2]));
+        const S t3 = fma_(m30, L.eg[0], fma_(m31, L.eg[1], fma_(m32, L.eg[2], L.eg[3])));
+        amix = fma_(L.ej[0], L.eg[0], fma_(L.ej[1], t1, fma_(L.ej[2], t2, L.ej[3] * t3)));
+        ig = fma_(i0, L.eg[0], fma_(i1, L.eg[1], fma_(i2, L.eg[2], i3 * L.eg[3]))); // 1 / d_g
+      }
       const bool diag = L.j == TR::row(L.g, v); // this lane's register v of tile (I, I) is a diagonal element
       const S one_d = diag ? S(1) : S(0);
       S bop[TILES], aop[TILES];
@@ -285,33 +362,35 @@ template <typename S, int M> struct Layout {
   static constexpr bool VEC_LOADS = Tr<S>::ROWS_CONTIGUOUS && (EDGE % 4 == 0);
 };
 
-// Column-major 32 x 32 (ld 32) -> tiles.
+// Column-major 32 x 32 (ld 32) at element offset `so` of the array behind `r` -> tiles.  ocol = j * 32 + row(g, 0).
 template <typename S, bool VEC>
-__device__ __forceinline__ Mat32<S> load32(const S *m, const LaneT<S> &L) {
-  using v4 = typename Tr<S>::v4;
-  Mat32<S> r;
+__device__ __forceinline__ Mat32<S> load32(const rsrc_t r, const unsigned ocol, const unsigned so) {
+  constexpr unsigned ES = sizeof(S);
+  Mat32<S> m;
 #pragma unroll
   for (int I = 0; I < 2; ++I)
 #pragma unroll
     for (int J = 0; J < 2; ++J) {
-      const S *col = m + (16 * J + L.j) * N + 16 * I;
       if constexpr (VEC) {
-        r.t[I][J] = *(const v4 *)(col + 4 * L.g);
+        m.t[I][J] = Mem<S>::ld4(r, (ocol + (unsigned)(16 * J * N + 16 * I)) * ES, so * ES);
       } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          r.t[I][J][v] = col[Tr<S>::row(L.g, v)];
+          m.t[I][J][v] = Mem<S>::ld(r, (ocol + (unsigned)(16 * J * N + 16 * I + Tr<S>::RSTEP * v)) * ES, so * ES);
       }
     }
-  return r;
+  return m;
 }
 
-// Waves per SIMD the register allocator is held to.  fp32: 3 (168 VGPRs, no scratch).  BASELINE's batch of 4096 is
-// 4 wavefronts per SIMD, so a fourth runs behind the first three; holding the allocator to 4 (128 VGPRs) keeps all
-// four resident but spills ~30 loop-invariant lane constants and schedules the rest more tightly: measured 2.61 ms
-// against 2.43 ms at 3 (bench.py --workload c4), 10.6 k against 8.1 k cycles of a SIMD per problem-stage.
+// Waves per SIMD the register allocator is held to.  fp32: 4 (128 VGPRs) -- BASELINE's batch of 4096 is exactly four
+// wavefronts per SIMD, and with three resident the fourth runs alone behind them at a lone wavefront's latency.  What
+// made 128 registers enough (the first version spilled ~30 loop-invariant lane constants there and was slower than
+// three wavefronts): every global access through a buffer descriptor in SGPRs + one 32-bit lane offset + an SGPR
+// stage offset + an immediate (no 64-bit pointer pair per access pattern), and the sweep's lane selectors as SGPR
+// masks instead of one-hot vectors.  bench.py --workload c4: 2.43 ms at 3 wavefronts with pointer addressing, 2.37
+// with buffer addressing, 2.22 at 4 (7 dwords of scratch left).
 #ifndef SIP_MT16_WAVES_F32
-#define SIP_MT16_WAVES_F32 3
+#define SIP_MT16_WAVES_F32 4
 #endif
 template <typename S> struct Waves { static constexpr int value = sizeof(S) == 4 ? SIP_MT16_WAVES_F32 : 2; };
 
@@ -337,16 +416,33 @@ void chain_factor_solve_mt16(
   L.lane = threadIdx.x & 63, L.j = L.lane & 15, L.g = L.lane >> 4;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    L.eg[k] = L.g == k ? S(1) : S(0);
-    L.ej[k] = L.j == TR::row(k, 0) ? S(1) : S(0);
+    if constexpr (sizeof(S) == 4) {
+      L.mg[k] = opaque_mask(L.g == k);
+      L.mj[k] = opaque_mask(L.j == TR::row(k, 0));
+    } else {
+      L.eg[k] = L.g == k ? S(1) : S(0);
+      L.ej[k] = L.j == TR::row(k, 0) ? S(1) : S(0);
+    }
   }
   const int j = L.j, g = L.g;
   const int acol = ctrl_of_col<S>(j); // control index of this lane's tile column (valid if < M)
-  const S *pm = mats + p * ((long)(T + 1) * LY::NODE + (long)T * LY::EDGE);
-  const S *pv = vecs + p * ((long)(T + 1) * LY::VNODE + (long)T * LY::VEDGE);
-  S *ps = sol + p * ((long)(T + 1) * LY::VNODE + (long)T * LY::VEDGE);
-  S *pg = gains + p * ((long)T * LY::GAIN);
-  S *pw = wsp + p * ((long)(T + 1) * LY::WSN);
+  constexpr unsigned ES = sizeof(S);
+  const long mats_len = (long)(T + 1) * LY::NODE + (long)T * LY::EDGE, vecs_len = (long)(T + 1) * LY::VNODE + (long)T * LY::VEDGE;
+  // one buffer descriptor per array, based at this wavefront's problem (SGPRs); every access below is
+  // descriptor + 32-bit lane offset + stage offset (SGPR) + immediate
+  const rsrc_t rM = make_rsrc(mats + p * mats_len, mats_len * ES), rV = make_rsrc(vecs + p * vecs_len, vecs_len * ES);
+  const rsrc_t rS = make_rsrc(sol + p * vecs_len, vecs_len * ES);
+  const rsrc_t rG = make_rsrc(gains + p * ((long)T * LY::GAIN), (long)T * LY::GAIN * ES);
+  const rsrc_t rW = make_rsrc(wsp + p * ((long)(T + 1) * LY::WSN), (long)(T + 1) * LY::WSN * ES);
+  const unsigned acolc = (unsigned)(acol < M ? acol : 0);
+  const unsigned uj = (unsigned)j, ug = (unsigned)g, r0 = (unsigned)TR::row(g, 0);
+  const unsigned ocol = uj * N + r0;     // column-major tile: element (row(g, 0), j)
+  const unsigned obcol = acolc * N + r0; // ... of B: the column of the control of tile column j
+  const unsigned orow = r0 * N + uj;     // transposed tile (A^T): element (j, row(g, 0)) of A
+  const unsigned octl = ug * N + uj;     // control rows: element (j, g) of B or M; control g + 4 v is 4 v N further
+  constexpr unsigned RS = (unsigned)TR::RSTEP;
+  auto ldM = [&](const unsigned vo, const unsigned so) { return Mem<S>::ld(rM, vo * ES, so * ES); };
+  auto ldV = [&](const unsigned vo, const unsigned so) { return Mem<S>::ld(rV, vo * ES, so * ES); };
 
   __shared__ S s_v[N], s_t[N], s_g[N], s_sd[N], s_sdi[N], s_x[N], s_z[N], s_gs[16], s_h[8], s_u[8];
   constexpr int LDM = TR::ROWS_CONTIGUOUS ? 36 : 33; // column stride of the mirror image (bank spread; 16-byte columns)
@@ -433,48 +529,49 @@ void chain_factor_solve_mt16(
           }
     }
     // spill W for the rollout: W is symmetric, tile (0, 1) is read back out of the dump of tile (1, 0)
-    v4 *wd = (v4 *)(pw + (long)i * LY::WSN);
-    wd[0 * 64 + L.lane] = W.t[0][0];
-    wd[1 * 64 + L.lane] = W.t[1][0];
-    wd[2 * 64 + L.lane] = W.t[1][1];
+    {
+      const unsigned so = (unsigned)i * LY::WSN * ES, vo = (unsigned)L.lane * 4u * ES;
+      Mem<S>::st4(W.t[0][0], rW, vo, so);
+      Mem<S>::st4(W.t[1][0], rW, vo + 256u * ES, so);
+      Mem<S>::st4(W.t[1][1], rW, vo + 512u * ES, so);
+    }
     lds_order();
     SIP_MT16_STAMP(10);
   };
 
   // ---- terminal node -------------------------------------------------------------------------
-  V = load32<S, VEC>(pm + (long)T * STG, L);
-  if (g == 0) {
-    s_v[j] = pv[(long)T * VSTG + j]; // v = q
-    s_v[16 + j] = pv[(long)T * VSTG + 16 + j];
-  }
   {
-    const S *nm = pm + (long)T * STG, *nv = pv + (long)T * VSTG;
-    const S dl0 = nm[N * N + j], dl1 = nm[N * N + 16 + j], c0 = nv[N + j], c1 = nv[N + 16 + j];
+    const unsigned sM = (unsigned)T * STG, sV = (unsigned)T * VSTG;
+    V = load32<S, VEC>(rM, ocol, sM);
+    const S qT0 = ldV(uj, sV), qT1 = ldV(uj + 16u, sV);
+    if (g == 0)
+      s_v[j] = qT0, s_v[16 + j] = qT1; // v = q
+    const S dl0 = ldM(uj + (unsigned)(N * N), sM), dl1 = ldM(uj + (unsigned)(N * N + 16), sM);
+    const S c0 = ldV(uj + (unsigned)N, sV), c1 = ldV(uj + (unsigned)(N + 16), sV);
     lds_order();
     finish_node(T, dl0, dl1, c0, c1);
   }
 
   // ---- backward recursion --------------------------------------------------------------------
   for (int i = T - 1; i >= 0; --i) {
-    const S *nm = pm + (long)i * STG;
-    const S *em = nm + LY::NODE;
-    const S *nv = pv + (long)i * VSTG;
-    const S *Bm = em + N * N, *Mm = Bm + N * M, *Rm = Mm + N * M;
-    const Mat32<S> A = load32<S, VEC>(em, L);
+    // element offsets of the stage's blocks inside the problem (SGPRs)
+    const unsigned sN = (unsigned)i * STG, sE = sN + LY::NODE, sB = sE + N * N, sMm = sB + N * M, sR = sMm + N * M;
+    const unsigned sV = (unsigned)i * VSTG;
+    const Mat32<S> A = load32<S, VEC>(rM, ocol, sE);
     // the node's and the edge's vectors: requested here, used at the bottom of the stage
-    const S dl0 = nm[N * N + j], dl1 = nm[N * N + 16 + j], c0 = nv[N + j], c1 = nv[N + 16 + j];
-    const S q0 = nv[j], q1 = nv[16 + j], rv = nv[LY::VNODE + (acol < M ? acol : 0)];
+    const S dl0 = ldM(uj + (unsigned)(N * N), sN), dl1 = ldM(uj + (unsigned)(N * N + 16), sN);
+    const S c0 = ldV(uj + (unsigned)N, sV), c1 = ldV(uj + (unsigned)(N + 16), sV);
+    const S q0 = ldV(uj, sV), q1 = ldV(uj + 16u, sV), rv = ldV(acolc + (unsigned)LY::VNODE, sV);
     // B (32 x M, ld 32): control acol on tile column j; columns of no control are zero
     Pair<S> B;
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
-      const S *col = Bm + (acol < M ? acol : 0) * N + 16 * I;
       if constexpr (VEC) {
-        B.t[I] = *(const v4 *)(col + 4 * g);
+        B.t[I] = Mem<S>::ld4(rM, (obcol + (unsigned)(16 * I)) * ES, sB * ES);
       } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          B.t[I][v] = col[TR::row(g, v)];
+          B.t[I][v] = ldM(obcol + (unsigned)(16 * I) + RS * v, sB);
       }
       if (acol >= M)
         B.t[I] = zero4<S>();
@@ -487,9 +584,9 @@ void chain_factor_solve_mt16(
     for (int v = 0; v < 4; ++v) {
       const int a = ctrl_of(g, v);
       const bool ok = v < VM && a < M;
-      if (v < VM) { // unconditional loads from clamped addresses, then a select (no branches)
-        const int ac = ok ? a : 0, cc = acol < M ? acol : 0;
-        const S h0 = Mm[ac * N + j], h1 = Mm[ac * N + 16 + j], rr = Rm[cc * M + ac];
+      if (v < VM) { // unconditional loads (a row a >= M of the 8-row window lies in the blocks behind: read, dropped)
+        const S h0 = ldM(octl + (unsigned)(4 * v * N), sMm), h1 = ldM(octl + (unsigned)(4 * v * N + 16), sMm);
+        const S rr = ldM(acolc * M + ug + (unsigned)(4 * v), sR);
         H.t[0][v] = ok ? h0 : S(0);
         H.t[1][v] = ok ? h1 : S(0);
         G[v] = (ok && acol < M) ? rr : (j == TR::row(g, v) ? S(1) : S(0));
@@ -506,8 +603,9 @@ void chain_factor_solve_mt16(
       const S g0 = s_v[j] + sum_groups(w0), g1 = s_v[16 + j] + sum_groups(w1);
       if (g == 0) {
         s_g[j] = g0, s_g[16 + j] = g1;
-        pw[(long)(i + 1) * LY::WSN + LY::WTILES * 256 + j] = g0;
-        pw[(long)(i + 1) * LY::WSN + LY::WTILES * 256 + 16 + j] = g1;
+        const unsigned so = ((unsigned)(i + 1) * LY::WSN + LY::WTILES * 256) * ES;
+        Mem<S>::st(g0, rW, uj * ES, so);
+        Mem<S>::st(g1, rW, (uj + 16u) * ES, so);
       }
     }
     SIP_MT16_STAMP(0);
@@ -603,15 +701,15 @@ void chain_factor_solve_mt16(
     kb = sum_groups(kb);
     // gains out: K (m x 32 column-major) | k
     {
-      S *gi = pg + (long)i * LY::GAIN;
+      const unsigned so = (unsigned)i * LY::GAIN * ES;
 #pragma unroll
       for (int v = 0; v < VM; ++v)
         if (ctrl_of(g, v) < M) {
-          gi[j * M + ctrl_of(g, v)] = K.t[0][v];
-          gi[(16 + j) * M + ctrl_of(g, v)] = K.t[1][v];
+          Mem<S>::st(K.t[0][v], rG, (uj * M + ug + (unsigned)(4 * v)) * ES, so);
+          Mem<S>::st(K.t[1][v], rG, (uj * M + ug + (unsigned)(4 * v + 16 * M)) * ES, so);
         }
       if (g == 0 && acol < M)
-        gi[M * N + acol] = kb;
+        Mem<S>::st(kb, rG, (acolc + (unsigned)(M * N)) * ES, so);
     }
     // v = q + A^T g + K^T h   (lqr.cpp:793-794)
     {
@@ -631,7 +729,7 @@ void chain_factor_solve_mt16(
     // V = Q + A^T F + K^T H   (lqr.cpp:715-719): tiles (0, 0), (1, 0), (1, 1) only -- the node tail keeps the lower
     // triangle and mirrors it, so tile (0, 1) is never read (10 MFMAs and a 16-byte load less per stage)
     {
-      const Mat32<S> Qm = load32<S, VEC>(nm, L); // (its tile (0, 1) is dead code)
+      const Mat32<S> Qm = load32<S, VEC>(rM, ocol, sN); // (its tile (0, 1) is dead code)
       V.t[0][0] = Qm.t[0][0], V.t[1][0] = Qm.t[1][0], V.t[1][1] = Qm.t[1][1];
     }
 #pragma unroll
@@ -663,9 +761,10 @@ void chain_factor_solve_mt16(
     mat_t_vec<S>(W, tr, w0, w1);
     const S g0 = s_v[j] + sum_groups(w0), g1 = s_v[16 + j] + sum_groups(w1);
     if (g == 0) {
-      const S x0 = pv[N + j] - pm[N * N + j] * g0, x1 = pv[N + 16 + j] - pm[N * N + 16 + j] * g1;
-      ps[j] = x0, ps[16 + j] = x1;
-      ps[N + j] = g0, ps[N + 16 + j] = g1;
+      const S x0 = ldV(uj + (unsigned)N, 0u) - ldM(uj + (unsigned)(N * N), 0u) * g0;
+      const S x1 = ldV(uj + (unsigned)(N + 16), 0u) - ldM(uj + (unsigned)(N * N + 16), 0u) * g1;
+      Mem<S>::st(x0, rS, uj * ES, 0u), Mem<S>::st(x1, rS, (uj + 16u) * ES, 0u);
+      Mem<S>::st(g0, rS, (uj + (unsigned)N) * ES, 0u), Mem<S>::st(g1, rS, (uj + (unsigned)(N + 16)) * ES, 0u);
       s_x[j] = x0, s_x[16 + j] = x1;
     }
   }
@@ -684,49 +783,50 @@ void chain_factor_solve_mt16(
   Mat32<S> Wc;  // W of the child
   S kb, gc0, gc1, cc0, cc1, dc0, dc1;
   auto fetch_K = [&](const int i) {
-    const S *gi = pg + (long)i * LY::GAIN;
+    const unsigned so = (unsigned)i * LY::GAIN * ES;
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        KT.t[I][v] = gi[(16 * I + TR::row(g, v)) * M + (acol < M ? acol : 0)]; // K(acol, r); other lanes: unused
-    kb = gi[M * N + (acol < M ? acol : 0)];
+      for (int v = 0; v < 4; ++v) // K(acol, r), r = 16 I + row(g, v); lanes of no control: unused
+        KT.t[I][v] = Mem<S>::ld(rG, (r0 * M + acolc + (unsigned)((16 * I + TR::RSTEP * v) * M)) * ES, so);
+    kb = Mem<S>::ld(rG, (acolc + (unsigned)(M * N)) * ES, so);
   };
   auto fetch_AB = [&](const int i) {
-    const S *em = pm + (long)i * STG + LY::NODE;
+    const unsigned sE = (unsigned)i * STG + LY::NODE;
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = 16 * I + TR::row(g, v);
-        AT.t[I][0][v] = em[r * N + j]; // A(j, r)
-        AT.t[I][1][v] = em[r * N + 16 + j];
+      for (int v = 0; v < 4; ++v) { // A(j, r), r = 16 I + row(g, v)
+        AT.t[I][0][v] = ldM(orow + (unsigned)((16 * I + TR::RSTEP * v) * N), sE);
+        AT.t[I][1][v] = ldM(orow + (unsigned)((16 * I + TR::RSTEP * v) * N + 16), sE);
       }
 #pragma unroll
     for (int v = 0; v < VM; ++v) {
-      const int a = ctrl_of(g, v), ac = a < M ? a : 0;
-      const S b0 = em[N * N + ac * N + j], b1 = em[N * N + ac * N + 16 + j]; // B(j, a)
+      const int a = ctrl_of(g, v);
+      // B(j, a), a = g + 4 v (a row a >= M of the window lies in the blocks behind B: read, then dropped)
+      const S b0 = ldM(octl + (unsigned)(N * N + 4 * v * N), sE), b1 = ldM(octl + (unsigned)(N * N + 4 * v * N + 16), sE);
       BT.t[0][v] = a < M ? b0 : S(0);
       BT.t[1][v] = a < M ? b1 : S(0);
     }
   };
   auto fetch_W = [&](const int i) { // the child's W, g and the node vectors of the child
-    const S *nm1 = pm + (long)(i + 1) * STG;
-    const S *nv1 = pv + (long)(i + 1) * VSTG;
-    const S *wn = pw + (long)(i + 1) * LY::WSN;
-    const v4 *wd = (const v4 *)wn;
-    Wc.t[0][0] = wd[0 * 64 + L.lane], Wc.t[1][0] = wd[1 * 64 + L.lane], Wc.t[1][1] = wd[2 * 64 + L.lane];
+    const unsigned sN1 = (unsigned)(i + 1) * STG, sV1 = (unsigned)(i + 1) * VSTG, sW = (unsigned)(i + 1) * LY::WSN;
+    const unsigned vl = (unsigned)L.lane * 4u * ES;
+    Wc.t[0][0] = Mem<S>::ld4(rW, vl, sW * ES), Wc.t[1][0] = Mem<S>::ld4(rW, vl + 256u * ES, sW * ES);
+    Wc.t[1][1] = Mem<S>::ld4(rW, vl + 512u * ES, sW * ES);
     // tile (0, 1) = tile (1, 0) transposed: element (row(g, v), 16 + j) is W(16 + j, row(g, v)), which the dump of
     // tile (1, 0) holds in register v' of lane (row(g, v), g') with row(g', v') = j
     {
-      const int gq = TR::ROWS_CONTIGUOUS ? (j >> 2) : (j & 3), vq = TR::ROWS_CONTIGUOUS ? (j & 3) : (j >> 2);
+      const unsigned gq = TR::ROWS_CONTIGUOUS ? (uj >> 2) : (uj & 3u), vq = TR::ROWS_CONTIGUOUS ? (uj & 3u) : (uj >> 2);
+      const unsigned ot = (16u * gq + r0) * 4u + vq;
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        Wc.t[0][1][v] = wn[(1 * 64 + 16 * gq + TR::row(g, v)) * 4 + vq];
+        Wc.t[0][1][v] = Mem<S>::ld(rW, (ot + (unsigned)((64 + TR::RSTEP * v) * 4)) * ES, sW * ES);
     }
-    gc0 = wn[LY::WTILES * 256 + j], gc1 = wn[LY::WTILES * 256 + 16 + j];
-    cc0 = nv1[N + j], cc1 = nv1[N + 16 + j];
-    dc0 = nm1[N * N + j], dc1 = nm1[N * N + 16 + j];
+    gc0 = Mem<S>::ld(rW, (uj + (unsigned)(LY::WTILES * 256)) * ES, sW * ES);
+    gc1 = Mem<S>::ld(rW, (uj + (unsigned)(LY::WTILES * 256 + 16)) * ES, sW * ES);
+    cc0 = ldV(uj + (unsigned)N, sV1), cc1 = ldV(uj + (unsigned)(N + 16), sV1);
+    dc0 = ldM(uj + (unsigned)(N * N), sN1), dc1 = ldM(uj + (unsigned)(N * N + 16), sN1);
   };
   if (T > 0) {
     fetch_K(0);
@@ -772,12 +872,12 @@ void chain_factor_solve_mt16(
     const S xn0 = z0 + (cc0 - dc0 * y0), xn1 = z1 + (cc1 - dc1 * y1);
     if (more)
       fetch_W(i + 1);
-    S *si = ps + (long)i * VSTG;
     if (g == 0) {
+      const unsigned so = (unsigned)i * VSTG * ES;
       if (acol < M)
-        si[2 * N + acol] = ub;
-      si[VSTG + j] = xn0, si[VSTG + 16 + j] = xn1;
-      si[VSTG + N + j] = y0, si[VSTG + N + 16 + j] = y1;
+        Mem<S>::st(ub, rS, (acolc + (unsigned)(2 * N)) * ES, so);
+      Mem<S>::st(xn0, rS, (uj + (unsigned)VSTG) * ES, so), Mem<S>::st(xn1, rS, (uj + (unsigned)(VSTG + 16)) * ES, so);
+      Mem<S>::st(y0, rS, (uj + (unsigned)(VSTG + N)) * ES, so), Mem<S>::st(y1, rS, (uj + (unsigned)(VSTG + N + 16)) * ES, so);
       s_x[j] = xn0, s_x[16 + j] = xn1;
     }
     lds_order();
