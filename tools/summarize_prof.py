@@ -97,8 +97,14 @@ def main():
             # GRBM_GUI_ACTIVE sums the 8 XCDs, 1024 SIMDs on the chip
             util = sq["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (sq["GRBM_GUI_ACTIVE"][0] / 8.0 * 1024.0)
             f.write(f"| MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) | {util:.3f} |\n")
-            flops = sq.get("SQ_INSTS_MFMA", (0, 0))[0] * 32 * 32 * 2 * 2
-            f.write(f"| MFMA flop/s (f32 32x32x2: 4096 flop each) | {flops / (float(krow['AverageNs']) * 1e-9) / 1e12:.1f} TFLOP/s of 157.3 peak |\n")
+            small = "mt16" in (kname or krow["Name"])  # chain_mt16: v_mfma_f32_16x16x4_f32, 2048 flop, 32 cycles each
+            per = 16 * 16 * 4 * 2 if small else 32 * 32 * 2 * 2
+            flops = sq.get("SQ_INSTS_MFMA", (0, 0))[0] * per
+            f.write(f"| MFMA flop/s (f32 {'16x16x4' if small else '32x32x2'}: {per} flop each) | "
+                    f"{flops / (float(krow['AverageNs']) * 1e-9) / 1e12:.1f} TFLOP/s of 157.3 peak |\n")
+            falg = bench.get("roofline", {}).get("algorithmic_flops_per_launch")
+            if falg:
+                f.write(f"| matrix-pipe flops per launch / algorithmic flops | {flops / falg:.2f} |\n")
         if "GRBM_GUI_ACTIVE" in sq:
             clk = sq["GRBM_GUI_ACTIVE"][0] / 8.0 / (float(krow["AverageNs"]) * 1e-9) / 1e9
             f.write(f"| effective clock = GRBM_GUI_ACTIVE / 8 / duration | {clk:.2f} GHz |\n")
