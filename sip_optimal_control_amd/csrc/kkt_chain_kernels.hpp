@@ -42,6 +42,30 @@ struct ChainKkt {
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
+// The reference's Newton-KKT benchmark family (benchmarks/newton_kkt_benchmark.cpp:59-80): every node has n states,
+// every edge m controls and (c, g) = (max(1, n / 2), max(1, 2 m)) constraint rows, the terminal node (c, g), interior
+// nodes none.  Kernels instantiated with FN > 0 take every dimension but the horizon from the template: the index
+// arithmetic, the loops over constraint rows and most of the branches of the generic code fold away (the
+// condensation is issue-bound: ~2 400 instructions per stage in the generic form).  FN = 0: dimensions from `ck`.
+template <int FN, int FM>
+__device__ __forceinline__ ChainKkt family_dims(ChainKkt ck) {
+  if constexpr (FN > 0) {
+    constexpr int c = FN / 2 > 0 ? FN / 2 : 1, g = 2 * FM > 0 ? 2 * FM : 1;
+    constexpr int n = FN, m = FM;
+    ck.n = n, ck.m = m, ck.cn = 0, ck.gn = 0, ck.cT = c, ck.gT = g, ck.ce = c, ck.ge = g;
+    ck.node_len = n * n;
+    ck.edge_len = 2 * n * n + 2 * n * m + m * m + (c + g) * (n + m);
+    ck.vecs_stage = 2 * n + m;
+    const int qlen = ck.sym ? n * (n + 1) / 2 : n * n, rlen = ck.sym ? m * (m + 1) / 2 : m * m;
+    ck.mats_stage = ck.split ? (qlen + n) + (n * m + rlen) : (n * n + n) + (n * n + 2 * n * m + m * m);
+    constexpr int cgn = c + g, cge = c + g;
+    ck.lds_item = (n * n + cgn * n + ck.edge_len + 1) / 2 * 2;
+    ck.lds_tail = (cgn * n + cge * (n + m) + 1) / 2 * 2;
+    ck.lds_rows = (cgn + cge + 1) / 2 * 2;
+  }
+  return ck;
+}
+
 // acc (+/-)= sum_k a[k] * b[k], k ascending (the order of the direct kernels)
 template <bool NEG>
 __device__ __forceinline__ double dot_seq(double acc, const double *a, const double *b, int rows) {
@@ -535,12 +559,13 @@ __device__ unsigned long long g_kkt_seg[16];
   } while (0)
 #endif
 constexpr int PIPE_U = 8;
-template <bool WITH_RHS>
+template <bool WITH_RHS, int FN = 0, int FM = 0>
 __global__ void __launch_bounds__(TPB)
-condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_all,
+condense_chain_pipe_kernel(const ChainKkt ck_in, const double *__restrict__ model_all,
                            const double *__restrict__ r1_all, const double *__restrict__ inv_all,
                            double *__restrict__ mats_all, const double *__restrict__ b_all,
                            double *__restrict__ vecs_all, const long batch, const int per_block) {
+  const ChainKkt ck = family_dims<FN, FM>(ck_in);
   extern __shared__ double sm[];
   double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows, *r1s = wr + ck.lds_rows;
   double *obuf = r1s + ((ck.n + ck.m + 1) & ~1);
@@ -620,13 +645,14 @@ condense_chain_pipe_kernel(const ChainKkt ck, const double *__restrict__ model_a
 // x, u, y scatter + multipliers of node i and edge i (helpers.cpp:817-892).  COLS: the instantiation
 // for several columns per launch (the two-phase form below) -- a kernel of its own so that the
 // single-column one keeps its 58 registers and eight wavefronts per SIMD.
-template <bool COLS = false>
+template <bool COLS = false, int FN = 0, int FM = 0>
 __global__ void __launch_bounds__(TPB)
-recover_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, const double *__restrict__ b_all,
+recover_chain_kernel(const ChainKkt ck_in, const double *__restrict__ model_all, const double *__restrict__ b_all,
                      const double *__restrict__ inv_all, const double *__restrict__ lqr_sol_all,
                      double *__restrict__ sol_all, const int32_t *__restrict__ status, long batch,
                      const int ncols = 1, const long b_col_stride = 0, const long lqr_col_stride = 0,
                      const long sol_col_stride = 0) {
+  const ChainKkt ck = family_dims<FN, FM>(ck_in);
   extern __shared__ double sm[];
   const int n = ck.n, m = ck.m, T = ck.T;
   const long p = blockIdx.x / (T + 1);

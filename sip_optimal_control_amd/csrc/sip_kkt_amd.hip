@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "generic_plan.hpp"
@@ -41,6 +42,10 @@ struct sip_kkt_plan {
   // the fused step hands the Riccati sweep ddyn_dx | ddyn_du in the model arena instead of copying
   // them into its inputs (sip_lqr_factor_solve_split); SIP_KKT_SPLIT=0 keeps the copy
   bool chain_split = false;
+  // > 0: the plan's dimensions are those of the reference's Newton-KKT benchmark family for (n, m) =
+  // (family / 100, family % 100) -- the hot chain kernels then run as the instantiation that has every dimension
+  // but the horizon as a constant (kkt_chain_kernels.hpp: family_dims); SIP_KKT_FAMILY=0 keeps the generic kernels
+  int family = 0;
   // ... and with Q_mod / R_mod as packed lower triangles (SIP_LQR_LAYOUT_SYMMETRIC) where the sweep has that kernel:
   // a second plan of the same shape, used by the fused step only; SIP_KKT_SYM=0 keeps the full squares
   sip_lqr_plan *chain_sym = nullptr;
@@ -150,6 +155,25 @@ bool uniform_constraints(const sip_kkt_plan &p) {
 }
 int even(int v) { return (v + 1) / 2 * 2; }
 
+// Calls f(integral_constant<FN>, integral_constant<FM>) for the plan's benchmark-family shape (family = 100 n + m),
+// f(0, 0) -- the generic kernels -- otherwise.
+template <class F> void family_dispatch(const int family, F &&f) {
+  auto at = [&](auto fn, auto fm) { f(fn, fm); };
+#define SIP_KKT_FAMILY_CASE(FN, FM)                                                      \
+  case 100 * FN + FM:                                                                    \
+    at(std::integral_constant<int, FN>{}, std::integral_constant<int, FM>{});           \
+    break;
+  switch (family) {
+    SIP_KKT_FAMILY_CASE(4, 1) SIP_KKT_FAMILY_CASE(4, 2) SIP_KKT_FAMILY_CASE(4, 3) SIP_KKT_FAMILY_CASE(4, 4)
+    SIP_KKT_FAMILY_CASE(6, 1) SIP_KKT_FAMILY_CASE(6, 2) SIP_KKT_FAMILY_CASE(6, 3) SIP_KKT_FAMILY_CASE(6, 4)
+    SIP_KKT_FAMILY_CASE(8, 1) SIP_KKT_FAMILY_CASE(8, 2) SIP_KKT_FAMILY_CASE(8, 3) SIP_KKT_FAMILY_CASE(8, 4)
+    SIP_KKT_FAMILY_CASE(12, 1) SIP_KKT_FAMILY_CASE(12, 2) SIP_KKT_FAMILY_CASE(12, 3) SIP_KKT_FAMILY_CASE(12, 4)
+  default:
+    at(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  }
+#undef SIP_KKT_FAMILY_CASE
+}
+
 // b != nullptr (fused factor+solve on the staged kernels): also builds q_mod, r_mod, c_mod.
 // split (chain kernels only): mats for sip_lqr_factor_solve_split -- no A | B in it.
 hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double *model, const double *w,
@@ -175,9 +199,11 @@ hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double
   const unsigned pipe_grid =
       pipe ? (unsigned)(((long)p->batch * p->N + p->chain_pipe - 1) / p->chain_pipe) : 0u;
   if (pipe && b != nullptr)
-    hipLaunchKernelGGL(sipamd::kkt::condense_chain_pipe_kernel<true>, dim3(pipe_grid), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch,
-                       p->chain_pipe);
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::condense_chain_pipe_kernel<true, decltype(fn)::value, decltype(fm)::value>),
+                         dim3(pipe_grid), dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, b,
+                         r.in1, (long)p->batch, p->chain_pipe);
+    });
   else if (pipe)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_pipe_kernel<false>, dim3(pipe_grid), dim3(sipamd::kkt::TPB),
                        p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, (const double *)nullptr,
@@ -226,8 +252,11 @@ hipError_t launch_rhs(const sip_kkt_plan *p, const Regions &r, const double *mod
 hipError_t launch_recover(const sip_kkt_plan *p, const Regions &r, const double *model, const double *b,
                           double *sol, const int32_t *status, hipStream_t s) {
   if (p->chain_kernels)
-    hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_recover, s, p->ck, model, b, r.inv, r.out, sol, status, (long)p->batch);
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::recover_chain_kernel<false, decltype(fn)::value, decltype(fm)::value>),
+                         dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_chain_recover, s, p->ck, model, b, r.inv, r.out,
+                         sol, status, (long)p->batch);
+    });
   else if (p->staged)
     hipLaunchKernelGGL(sipamd::kkt::recover_staged_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
                        p->lds_recover, s, p->meta, model, b, r.inv, r.out, sol, status, (long)p->batch);
@@ -504,6 +533,14 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
                       len_mid / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB &&
                       len_last / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB;
     p->chain_pipe = fits && per > 0 ? per : 0;
+    {
+      const int fn = ck.n, fm = ck.m, fc = std::max(1, fn / 2), fg = std::max(1, 2 * fm);
+      const char *fe = std::getenv("SIP_KKT_FAMILY");
+      const bool shape = (fn == 4 || fn == 6 || fn == 8 || fn == 12) && fm >= 1 && fm <= 4;
+      if (shape && ck.cn == 0 && ck.gn == 0 && ck.cT == fc && ck.gT == fg && ck.ce == fc && ck.ge == fg &&
+          !(fe != nullptr && fe[0] == '0'))
+        p->family = 100 * fn + fm;
+    }
     const char *se = std::getenv("SIP_KKT_SPLIT");
     p->chain_split = E > 0 && sip_lqr_has_split(p->chain) == 1 && !(se != nullptr && se[0] == '0');
     const char *sy = std::getenv("SIP_KKT_SYM");
@@ -520,6 +557,8 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
   p->name += p->chain_kernels ? " + chain condensation" : p->staged ? " + staged condensation" : " + direct condensation";
   if (p->chain_split)
     p->name += p->chain_sym != nullptr ? " (A|B in place, Q|R packed)" : " (A|B in place)";
+  if (p->family > 0)
+    p->name += " [benchmark-family instantiation]";
 
   std::vector<int> ints;
   auto pi = [&](const std::vector<int> &v) {
