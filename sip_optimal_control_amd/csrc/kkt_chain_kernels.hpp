@@ -493,9 +493,9 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
 // WITH_RHS: also q_mod / r_mod / c_mod from b.  MATS = false (the split solve path): ONLY those --
 // the Jacobians of the stage are staged, no Q_mod / M_mod / R_mod / A / B work, `status` problems
 // with a failed factorization are skipped.
-template <bool WITH_RHS, bool MATS = true>
+template <bool WITH_RHS, bool MATS = true, int FN = 0, int FM = 0>
 __global__ void __launch_bounds__(TPB)
-condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, const double *__restrict__ r1_all,
+condense_chain_kernel(const ChainKkt ck_in, const double *__restrict__ model_all, const double *__restrict__ r1_all,
                       const double *__restrict__ inv_all, double *__restrict__ mats_all,
                       const double *__restrict__ b_all, double *__restrict__ vecs_all, long batch,
                       const int32_t *__restrict__ status = nullptr, const int ncols = 1,
@@ -504,6 +504,7 @@ condense_chain_kernel(const ChainKkt ck, const double *__restrict__ model_all, c
   // b_all + j * b_col_stride, its q_mod / r_mod / c_mod go to vecs_all + j * vecs_col_stride; the
   // Jacobians of the stage are staged once for all columns.
   static_assert(MATS || WITH_RHS, "nothing to do");
+  const ChainKkt ck = family_dims<FN, FM>(ck_in);
   extern __shared__ double sm[];
   // wr: one block of lds_rows per right-hand-side column when there are several (MATS = false)
   double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows,

@@ -23,4 +23,13 @@ const KernelEntry *SIP_CAT(qw16_extra_slice_, SIP_QW16_SLICE)(int *count) {
   *count = (int)(sizeof(kSlice) / sizeof(kSlice[0]));
   return kSlice;
 }
+// the split form (A | B read where the model callback left them, qw16_split.hip) of the slice's share of the
+// staged shapes: with these, sip_lqr_factor_solve_split covers every shape n <= 15, m <= 8
+namespace {
+const SplitEntry kSplitSlice[] = {QW16_SLICE_SPLIT_ENTRIES};
+}
+const SplitEntry *SIP_CAT(qw16_extra_split_slice_, SIP_QW16_SLICE)(int *count) {
+  *count = (int)(sizeof(kSplitSlice) / sizeof(kSplitSlice[0]));
+  return kSplitSlice;
+}
 } // namespace sipamd

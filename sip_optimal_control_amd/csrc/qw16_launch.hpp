@@ -93,13 +93,22 @@ hipError_t launch_qw16_split(long batch, int T, const void *mats, const void *ab
                      (const double *)ab, ab_pstride, ab_sstride SIP_STAMP_PASS);
   return hipGetLastError();
 }
+struct SplitEntry {
+  int n, m;
+  launch_split_t launch;
+  int layout; // SIP_LQR_LAYOUT_* of the [Q | delta | M | R] blocks
+};
+#define QW16_SPLIT(N, M) {N, M, &sipamd::launch_qw16_split<N, M>, SIP_LQR_LAYOUT_FULL}
+#define QW16_SPLIT_SYM(N, M) {N, M, &sipamd::launch_qw16_split<N, M, true>, SIP_LQR_LAYOUT_SYMMETRIC}
 launch_split_t find_split_launch(int n, int m, int layout = 0); // qw16_split.hip; nullptr: no split kernel for the shape / layout
 long split_mats_stage(int n, int m, int layout = 0);            // scalars of [Q | delta | M | R]
 
 // The shapes n <= 16, m <= 8 that sip_lqr_amd.hip does not instantiate itself live in eight slices
 // of qw16_extra.hip (compiled in parallel): slice s defines qw16_extra_slice_<s>.
 constexpr int kQw16ExtraSlices = 8;
-#define SIP_QW16_DECLARE_SLICE(S) const KernelEntry *qw16_extra_slice_##S(int *count);
+#define SIP_QW16_DECLARE_SLICE(S)                                \
+  const KernelEntry *qw16_extra_slice_##S(int *count);          \
+  const SplitEntry *qw16_extra_split_slice_##S(int *count); // the split kernels of the slice's staged shapes
 SIP_QW16_DECLARE_SLICE(0) SIP_QW16_DECLARE_SLICE(1) SIP_QW16_DECLARE_SLICE(2) SIP_QW16_DECLARE_SLICE(3)
 SIP_QW16_DECLARE_SLICE(4) SIP_QW16_DECLARE_SLICE(5) SIP_QW16_DECLARE_SLICE(6) SIP_QW16_DECLARE_SLICE(7)
 #undef SIP_QW16_DECLARE_SLICE

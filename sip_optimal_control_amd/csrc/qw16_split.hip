@@ -11,17 +11,10 @@
 
 namespace sipamd {
 
-struct SplitEntry {
-  int n, m;
-  launch_split_t launch;
-  int layout; // SIP_LQR_LAYOUT_* of the [Q | delta | M | R] blocks
-};
 const SplitEntry *qw16_split_slice_1(int *count);
 const SplitEntry *qw16_split_slice_2(int *count);
 const SplitEntry *qw16_split_slice_3(int *count);
 
-#define QW16_SPLIT(N, M) {N, M, &launch_qw16_split<N, M>, SIP_LQR_LAYOUT_FULL}
-#define QW16_SPLIT_SYM(N, M) {N, M, &launch_qw16_split<N, M, true>, SIP_LQR_LAYOUT_SYMMETRIC}
 // the staged shapes of the reference's Newton-KKT benchmark grid (newton_kkt_benchmark.cpp:264-273:
 // n in {4, 6, 8}, m in {1, 2, 3, 4}) and n = 12 (the f1 shape of bench.py and its fewer-control relatives)
 #if SIP_QW16_SPLIT_SLICE == 0
@@ -37,6 +30,16 @@ launch_split_t find_split_launch(int n, int m, int layout) {
 #if !defined(SIP_QW16_QUICK) && !defined(SIP_QW16_NO_EXTRA) // tools/ab_build.sh, tools/diag_build.sh link slice 0 alone
   typedef const SplitEntry *(*slice_fn)(int *);
   for (const slice_fn fn : {qw16_split_slice_1, qw16_split_slice_2, qw16_split_slice_3}) {
+    int count = 0;
+    const SplitEntry *more = fn(&count);
+    for (int k = 0; k < count; ++k)
+      if (more[k].n == n && more[k].m == m && more[k].layout == layout)
+        return more[k].launch;
+  }
+  // every other staged shape n <= 15, m <= 8: beside its fused kernel in the slices of qw16_extra.hip
+  for (const slice_fn fn : {qw16_extra_split_slice_0, qw16_extra_split_slice_1, qw16_extra_split_slice_2,
+                            qw16_extra_split_slice_3, qw16_extra_split_slice_4, qw16_extra_split_slice_5,
+                            qw16_extra_split_slice_6, qw16_extra_split_slice_7}) {
     int count = 0;
     const SplitEntry *more = fn(&count);
     for (int k = 0; k < count; ++k)

@@ -205,9 +205,11 @@ hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double
                          r.in1, (long)p->batch, p->chain_pipe);
     });
   else if (pipe)
-    hipLaunchKernelGGL(sipamd::kkt::condense_chain_pipe_kernel<false>, dim3(pipe_grid), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, (const double *)nullptr,
-                       (double *)nullptr, (long)p->batch, p->chain_pipe);
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::condense_chain_pipe_kernel<false, decltype(fn)::value, decltype(fm)::value>),
+                         dim3(pipe_grid), dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0,
+                         (const double *)nullptr, (double *)nullptr, (long)p->batch, p->chain_pipe);
+    });
   else if (p->chain_kernels && b != nullptr)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
                        p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
@@ -237,9 +239,11 @@ hipError_t launch_merge(const sip_kkt_plan *p, const Regions &r, int32_t *status
 hipError_t launch_rhs(const sip_kkt_plan *p, const Regions &r, const double *model, const double *b,
                       const int32_t *status, hipStream_t s) {
   if (p->chain_kernels)
-    hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false>), dim3(node_grid(p)),
-                       dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, p->ck, model, (const double *)nullptr,
-                       r.inv, r.in0, b, r.in1, (long)p->batch, status);
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false, decltype(fn)::value, decltype(fm)::value>),
+                         dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, p->ck, model,
+                         (const double *)nullptr, r.inv, r.in0, b, r.in1, (long)p->batch, status);
+    });
   else if (p->staged)
     hipLaunchKernelGGL(sipamd::kkt::rhs_staged_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_rhs, s,
                        p->meta, model, b, r.inv, r.in1, status, (long)p->batch);
@@ -919,10 +923,13 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
     const int rhs_cols = 1 + (int)std::min<size_t>((size_t)(th - 1), (64 * 1024 - p->lds_chain_condense) / std::max<size_t>(rhs_col_lds, 1));
     for (int c0 = 0; c0 < th; c0 += rhs_cols) {
       const int nc = std::min(rhs_cols, th - c0);
-      hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false>), dim3(node_grid(p)),
-                         dim3(sipamd::kkt::TPB), p->lds_chain_condense + rhs_col_lds * (size_t)(nc - 1), s, p->ck,
-                         d_model, (const double *)nullptr, r.inv, r.in0, (const double *)t.J + (size_t)c0 * colJ,
-                         t.vecs_cols + (size_t)c0 * colV, (long)p->batch, (const int32_t *)d_status, nc, colJ, colV);
+      family_dispatch(p->family, [&](auto fn, auto fm) {
+        hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false, decltype(fn)::value, decltype(fm)::value>),
+                           dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                           p->lds_chain_condense + rhs_col_lds * (size_t)(nc - 1), s, p->ck, d_model,
+                           (const double *)nullptr, r.inv, r.in0, (const double *)t.J + (size_t)c0 * colJ,
+                           t.vecs_cols + (size_t)c0 * colV, (long)p->batch, (const int32_t *)d_status, nc, colJ, colV);
+      });
     }
     if ((e = hipGetLastError()) != hipSuccess)
       return report(e, "sip_kkt_factor_theta(rhs)");
@@ -937,15 +944,22 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
     for (int c0 = 0; c0 < th; c0 += rec_cols) {
       const int nc = std::min(rec_cols, th - c0);
       if (nc > 1)
-        hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                           p->lds_chain_recover + rec_col_lds * (size_t)(nc - 1), s, p->ck, d_model,
-                           (const double *)t.J + (size_t)c0 * colJ, r.inv, (const double *)t.lsol_cols + (size_t)c0 * colV,
-                           t.KJ + (size_t)c0 * colJ, (const int32_t *)d_status, (long)p->batch, nc, colJ, colV, colJ);
+        family_dispatch(p->family, [&](auto fn, auto fm) {
+          hipLaunchKernelGGL((sipamd::kkt::recover_chain_kernel<true, decltype(fn)::value, decltype(fm)::value>),
+                             dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                             p->lds_chain_recover + rec_col_lds * (size_t)(nc - 1), s, p->ck, d_model,
+                             (const double *)t.J + (size_t)c0 * colJ, r.inv,
+                             (const double *)t.lsol_cols + (size_t)c0 * colV, t.KJ + (size_t)c0 * colJ,
+                             (const int32_t *)d_status, (long)p->batch, nc, colJ, colV, colJ);
+        });
       else
-        hipLaunchKernelGGL(sipamd::kkt::recover_chain_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                           p->lds_chain_recover, s, p->ck, d_model, (const double *)t.J + (size_t)c0 * colJ, r.inv,
-                           (const double *)t.lsol_cols + (size_t)c0 * colV, t.KJ + (size_t)c0 * colJ,
-                           (const int32_t *)d_status, (long)p->batch, 1, colJ, colV, colJ);
+        family_dispatch(p->family, [&](auto fn, auto fm) {
+          hipLaunchKernelGGL((sipamd::kkt::recover_chain_kernel<false, decltype(fn)::value, decltype(fm)::value>),
+                             dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_chain_recover, s, p->ck, d_model,
+                             (const double *)t.J + (size_t)c0 * colJ, r.inv,
+                             (const double *)t.lsol_cols + (size_t)c0 * colV, t.KJ + (size_t)c0 * colJ,
+                             (const int32_t *)d_status, (long)p->batch, 1, colJ, colV, colJ);
+        });
     }
     if ((e = hipGetLastError()) != hipSuccess)
       return report(e, "sip_kkt_factor_theta(recover)");

@@ -42,6 +42,31 @@ def test_split_equals_packed_and_oracle(oracle_lib, n, m, T, batch):
     assert _rel(sol2.cpu().numpy(), ref_sol) <= TOL and _rel(gains2.cpu().numpy(), ref_gains) <= TOL
 
 
+@pytest.mark.parametrize("n", list(range(1, 16)))
+def test_every_staged_shape_with_whole_pieces_has_a_split_kernel(n):
+    """the in-place A | B form for every staged shape n <= 15, m <= 8 whose A | B block is a whole
+    number of 16-byte pieces (n (n + m) even; the others would start on odd 8-byte offsets at every other stage and
+    keep the copy).  Bitwise equal to the packed sweep."""
+    for m in range(1, 9):
+        T, batch = 5, 6
+        solver, mats, vecs = _problem(n, m, T, batch, seed=100 * n + m)
+        if not BatchedChainLQR_full_build(solver):
+            pytest.skip("single-kernel diagnostic build")
+        assert solver.has_split == (n * (n + m) % 2 == 0), (n, m)
+        if not solver.has_split:
+            continue
+        sol, gains, status = (t.clone() for t in solver.factor_solve(mats, vecs))
+        qmr, ab = solver.split_inputs(mats)
+        sol2, gains2, status2 = solver.factor_solve_split(qmr, ab, vecs)
+        torch.cuda.synchronize()
+        assert torch.equal(status, status2) and int(status.abs().sum()) == 0, (n, m)
+        assert torch.equal(sol, sol2) and torch.equal(gains, gains2), (n, m)
+
+
+def BatchedChainLQR_full_build(solver):
+    return "qw16" in solver.kernel_name
+
+
 def test_split_reads_strided_jacobians():
     """A | B inside a larger per-stage record of a larger per-problem arena (what the model arena of the
     Newton-KKT step looks like): strides come from the caller."""
@@ -82,7 +107,8 @@ def test_split_statuses():
 
 def test_unsupported_plans_say_so():
     from sip_optimal_control_amd import BatchedChainLQR
-    assert not BatchedChainLQR(5, 3, 4, 2, device="cuda:0").has_split      # a direct kernel
+    assert not BatchedChainLQR(16, 3, 4, 2, device="cuda:0").has_split     # a direct kernel
+    assert not BatchedChainLQR(5, 2, 4, 2, device="cuda:0").has_split      # n (n + m) odd: A | B not in 16-byte pieces
     assert not BatchedChainLQR(32, 8, 4, 2, dtype=torch.float32, device="cuda:0").has_split
 
 

@@ -217,6 +217,27 @@ def test_packed_condensation_gives_the_same_bits(monkeypatch, n, m, T):
     assert float(np.abs(sol_p.cpu().numpy() - ref).max() / np.abs(ref).max()) <= 1e-9
 
 
+@pytest.mark.parametrize("n,m", [(10, 5), (14, 2), (7, 7), (15, 1), (2, 8)])
+def test_in_place_jacobians_outside_the_benchmark_grid(monkeypatch, n, m):
+    """the step reads ddyn_dx | ddyn_du in place for every staged shape whose A | B block is a whole
+    number of 16-byte pieces, not only the benchmark grid -- the same bits as the copying step."""
+    dims = rk.newton_kkt_dims(n, m, 6)
+    batch = 4
+    arrays = rk.newton_kkt_problem(dims, seed=3 * n + m, batch=batch, r2_max=1e2)
+    d = _dev(*arrays)
+    kkt = _make(dims, batch)
+    assert "(A|B in place" in kkt.kernel_name
+    sol, st = kkt.factor_solve(*d)
+    assert st.cpu().tolist() == [0] * batch
+    monkeypatch.setenv("SIP_KKT_SPLIT", "0")
+    copying = _make(dims, batch)
+    assert "(A|B in place" not in copying.kernel_name
+    assert torch.equal(copying.factor_solve(*d)[0], sol)
+    ref, ref_status = KKTOracle(dims).batch(*arrays)
+    assert (ref_status == 0).all()
+    assert (np.abs(sol.cpu().numpy() - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= REL
+
+
 def test_condensation_variants_agree_bitwise(monkeypatch):
     """The table-driven LDS-staged kernels and the direct kernels (fallback for items too large for
     LDS) accumulate every element in the same order with the same operations; the uniform-chain
