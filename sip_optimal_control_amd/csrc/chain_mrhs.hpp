@@ -17,6 +17,9 @@
 //
 // Per-column state that the rollout needs (g, h of the child node and k of the edge) goes to a
 // column workspace: cws[problem][node i][col][g (N) | h (N) | k of edge i (M)].
+//
+// A launch of `ncols_launch` columns is a grid of (batch / 4) x ceil(ncols_launch / P) single-wave workgroups:
+// wavefront (b, y) carries columns [y P, y P + P) of problems 4 b .. 4 b + 3.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -28,8 +31,13 @@ template <int N, int M, bool WPACK, int P>
 __global__ __launch_bounds__(64) void chain_solve_mrhs_qw16(
     const double *__restrict__ mats, const double *__restrict__ vecs_cols, double *__restrict__ sol_cols,
     const double *__restrict__ gains, const double *__restrict__ wsp, const double *__restrict__ gfac,
-    double *__restrict__ cws, const int *__restrict__ status, const long batch, const int T, const int ncols,
+    double *__restrict__ cws, const int *__restrict__ status, const long batch, const int T, const int ncols_launch,
     const long col_stride /* scalars between two columns of vecs_cols / sol_cols */) {
+  // blockIdx.y: the group of P columns this wavefront carries (the columns are independent: more wavefronts per
+  // SIMD than one launch of batch / 4 single-wave workgroups gives, at the price of fetching the stage operands
+  // once per group)
+  const int col0 = (int)blockIdx.y * P;
+  const int ncols = ncols_launch - col0 < P ? ncols_launch - col0 : P;
   static_assert(N >= 1 && N <= 16 && M >= 1 && M <= 16 && P >= 1 && P <= 16, "");
   using L = ChainLayout<N, M>;
   using C = StagedCfg<N, M, WPACK>;
@@ -51,12 +59,12 @@ __global__ __launch_bounds__(64) void chain_solve_mrhs_qw16(
   const long mats_len = (long)(T + 1) * L::NODE + (long)T * L::EDGE;
   const long vecs_len = (long)(T + 1) * L::VNODE + (long)T * L::VEDGE;
   const double *pm = mats + p * mats_len;
-  const double *pv = vecs_cols + p * vecs_len;
-  double *ps = sol_cols + p * vecs_len;
+  const double *pv = vecs_cols + p * vecs_len + col0 * col_stride;
+  double *ps = sol_cols + p * vecs_len + col0 * col_stride;
   const double *pg = gains + p * ((long)T * L::GAIN);
   const double *pw = wsp + p * ((long)(T + 1) * WSN);
   const double *pf = gfac + p * ((long)T * (M * M + M));
-  double *pc = cws + p * ((long)(T + 1) * ncols * CW);
+  double *pc = cws + p * ((long)(T + 1) * ncols_launch * CW) + col0 * CW; // below: slot (i, col) at (i * ncols_launch + col) * CW
 
   int woff[N]; // S(row c, k) inside a spill slot (packed lower triangle or full, as the factor left it)
   sfor<0, N>([&](auto kk) {
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(64) void chain_solve_mrhs_qw16(
     dotv<N, true>(acc, phi, o.Srow);
     const double sphi = sum4(acc);
     if (live && isM)
-      pc[((long)i * ncols + col) * CW + N + c] = sphi;
+      pc[((long)i * ncols_launch + col) * CW + N + c] = sphi;
     return sdi * (phi - sphi);
   };
 
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(64) void chain_solve_mrhs_qw16(
       if (col < ncols) {
         const double gd = v_[col] + wt[col]; // g = v_c + W t  (lqr.cpp:780-781)
         if (live && isM)
-          pc[((long)(i + 1) * ncols + col) * CW + c] = gd;
+          pc[((long)(i + 1) * ncols_launch + col) * CW + c] = gd;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         dotv<N, true>(acc, gd, ed.Bcol);
         const double hd = ed.rvec[col] + sum4(acc); // h = r + B^T g  (:783-784), lane j < M holds h_j
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(64) void chain_solve_mrhs_qw16(
           kf[j] = __builtin_fma(-ed.rinv[j], a, kf[j]);
         });
         if (live && c == 0) {
-          double *kd = pc + ((long)i * ncols + col) * CW + 2 * N;
+          double *kd = pc + ((long)i * ncols_launch + col) * CW + 2 * N;
           sfor<0, M>([&](auto jj) { kd[decltype(jj)::value] = -kf[decltype(jj)::value]; });
         }
         double acc2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -217,9 +225,9 @@ __global__ __launch_bounds__(64) void chain_solve_mrhs_qw16(
     sfor<0, P>([&](auto cc) {
       constexpr int col = decltype(cc)::value;
       if (col < ncols) {
-        o.kk0[col] = pc[((long)i * ncols + col) * CW + 2 * N + cu];
-        o.gg[col] = pc[((long)(i + 1) * ncols + col) * CW + cm];
-        o.hh[col] = pc[((long)(i + 1) * ncols + col) * CW + N + cm];
+        o.kk0[col] = pc[((long)i * ncols_launch + col) * CW + 2 * N + cu];
+        o.gg[col] = pc[((long)(i + 1) * ncols_launch + col) * CW + cm];
+        o.hh[col] = pc[((long)(i + 1) * ncols_launch + col) * CW + N + cm];
       }
     });
   };

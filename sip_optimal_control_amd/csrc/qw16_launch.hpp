@@ -29,6 +29,10 @@ typedef hipError_t (*launch_mrhs_t)(long batch, int T, const void *mats, const v
                                     const void *gains, const void *ws, const void *gfac, void *cws,
                                     const int32_t *status, int ncols, long col_stride, hipStream_t stream);
 constexpr int kMrhsColumns = 8; // columns one multi-rhs launch carries
+#ifndef SIP_MRHS_GROUP
+#define SIP_MRHS_GROUP 4
+#endif
+constexpr int kMrhsGroup = SIP_MRHS_GROUP; // ... of which one wavefront carries this many (chain_mrhs.hpp)
 
 struct KernelEntry {
   int dtype, n, m;
@@ -45,8 +49,8 @@ hipError_t launch_mrhs_qw16(long batch, int T, const void *mats, const void *vec
                             int ncols, long col_stride, hipStream_t stream) {
   if (ncols < 1 || ncols > kMrhsColumns)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL((chain_solve_mrhs_qw16<N, M, WPACK, kMrhsColumns>), dim3((unsigned)((batch + 3) / 4)), dim3(64),
-                     0, stream, (const double *)mats, (const double *)vecs_cols, (double *)sol_cols,
+  hipLaunchKernelGGL((chain_solve_mrhs_qw16<N, M, WPACK, kMrhsGroup>),
+                     dim3((unsigned)((batch + 3) / 4), (unsigned)((ncols + kMrhsGroup - 1) / kMrhsGroup)), dim3(64), 0, stream, (const double *)mats, (const double *)vecs_cols, (double *)sol_cols,
                      (const double *)gains, (const double *)ws, (const double *)gfac, (double *)cws,
                      (const int *)status, batch, T, ncols, col_stride);
   return hipGetLastError();

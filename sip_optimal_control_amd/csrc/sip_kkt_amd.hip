@@ -19,6 +19,7 @@
 #include "kkt_chain_kernels.hpp"
 #include "kkt_kernels.hpp"
 #include "kkt_theta_kernels.hpp"
+#include "kkt_theta_chain_kernels.hpp"
 
 struct sip_kkt_plan {
   int64_t batch = 0;
@@ -58,6 +59,11 @@ struct sip_kkt_plan {
   long theta_len = 0;
   void *d_theta_longs = nullptr;
   sipamd::kkt::ThetaMeta theta_meta{};
+  // uniform chains: the fused theta passes of kkt_theta_chain_kernels.hpp (J_theta never assembled);
+  // SIP_KKT_THETA_FUSED=0 keeps the generic passes
+  bool chain_theta = false;
+  sipamd::kkt::ChainTheta ct{};
+  size_t lds_theta_rhs = 0, lds_theta_recover = 0, lds_theta_dot = 0;
   bool staged = false; // LDS-staged kernels (false: items too large for LDS, or SIP_KKT_VARIANT=direct)
   size_t lds_condense = 0, lds_rhs = 0, lds_recover = 0;
   std::string name;
@@ -800,12 +806,17 @@ struct ThetaRegions {
   double *J, *KJ, *S, *rhs_sw, *sol_sw, *vecs_cols, *lsol_cols; // the last two: chain plans only
   void *cws; // column workspace of sip_lqr_solve_multi (chain plans)
 };
+size_t theta_j_scalars(const sip_kkt_plan *p) { // per problem
+  const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, th = (size_t)p->theta_dim;
+  return p->chain_theta ? (size_t)p->N * (th * th + th) : skkt * th;
+}
 ThetaRegions theta_regions(const sip_kkt_plan *p, void *theta_work) {
   const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, B = (size_t)p->batch;
   char *w = (char *)theta_work;
   ThetaRegions r;
   size_t cur = 0;
-  r.J = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt * p->theta_dim);
+  // (the fused chain passes keep stage partials here instead of J_theta: S_part (N p^2) then d_part (N p) per problem)
+  r.J = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * theta_j_scalars(p));
   r.KJ = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt * p->theta_dim);
   r.S = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * p->theta_dim * p->theta_dim);
   r.rhs_sw = (double *)(w + cur), cur = align256(cur + sizeof(double) * B * skkt);
@@ -860,6 +871,36 @@ int sip_kkt_plan_set_theta(sip_kkt_plan *p, int theta_dim) {
     return report(he, "sip_kkt_plan_set_theta");
   p->theta_len = at, p->theta_dim = th;
   p->theta_meta.p = th, p->theta_meta.theta_len = at;
+  if (p->chain_kernels && E >= 1) {
+    const sipamd::kkt::ChainKkt &ck = p->ck;
+    sipamd::kkt::ChainTheta &ct = p->ct;
+    ct.p = th, ct.theta_len = at;
+    ct.node_len = (ck.n + ck.cn + ck.gn + th) * th;
+    ct.edge_len = (2 * ck.n + ck.m + ck.ce + ck.ge + th) * th;
+    ct.lds_item = even(std::max(ct.node_len + ct.edge_len, (ck.n + ck.cT + ck.gT + th) * th));
+    bool as_assumed = true; // the blocks of stage i are one item at i (node_len + edge_len), in ThetaBlock order
+    for (int i = 0; i < N && as_assumed; ++i) {
+      const long base = (long)i * (ct.node_len + ct.edge_len);
+      const int c = i == E ? ck.cT : ck.cn, g = i == E ? ck.gT : ck.gn;
+      as_assumed = p->toff[TH_N_X][i] == base && p->toff[TH_N_C][i] == base + (long)ck.n * th &&
+                   p->toff[TH_N_G][i] == base + (long)(ck.n + c) * th &&
+                   p->toff[TH_N_TT][i] == base + (long)(ck.n + c + g) * th;
+      if (as_assumed && i < E)
+        as_assumed = p->toff[TH_E_X][i] == base + ct.node_len && p->toff[TH_E_U][i] == base + ct.node_len + (long)ck.n * th &&
+                     p->toff[TH_E_DYN][i] == base + ct.node_len + (long)(ck.n + ck.m) * th &&
+                     p->toff[TH_E_C][i] == base + ct.node_len + (long)(2 * ck.n + ck.m) * th &&
+                     p->toff[TH_E_G][i] == base + ct.node_len + (long)(2 * ck.n + ck.m + ck.ce) * th &&
+                     p->toff[TH_E_TT][i] == base + ct.node_len + (long)(2 * ck.n + ck.m + ck.ce + ck.ge) * th &&
+                     p->parents[i] == i && p->children[i] == i + 1;
+    }
+    const size_t per = (size_t)ck.n + ck.m, R = (size_t)ck.lds_rows, P = (size_t)th;
+    p->lds_theta_rhs = sizeof(double) * ((size_t)ck.lds_tail + ct.lds_item + R + P * R);
+    p->lds_theta_recover = sizeof(double) * ((size_t)ck.lds_tail + ct.lds_item + P * per + P * ck.n + P * R + R);
+    p->lds_theta_dot = sizeof(double) * ((size_t)ct.lds_item + per + ck.n + R);
+    const char *fe = std::getenv("SIP_KKT_THETA_FUSED");
+    p->chain_theta = as_assumed && std::max(p->lds_theta_rhs, p->lds_theta_recover) <= 64 * 1024 &&
+                     !(fe != nullptr && fe[0] == '0');
+  }
   for (int b = 0; b < TH_NUM_BLOCKS; ++b)
     p->theta_meta.to[b] = (const long *)p->d_theta_longs + where[b];
   return SIP_LQR_OK;
@@ -880,8 +921,8 @@ size_t sip_kkt_theta_work_bytes(const sip_kkt_plan *p) {
   const size_t skkt = (size_t)p->x_dim + p->y_dim + p->z_dim, B = (size_t)p->batch, th = (size_t)p->theta_dim;
   const size_t cols = p->chain_kernels ? align256(sizeof(double) * B * (size_t)p->in1_len * th) : 0;
   const size_t cws = p->chain_kernels ? align256(sip_lqr_solve_multi_workspace_bytes(p->chain, p->theta_dim)) : 0;
-  return 2 * align256(sizeof(double) * B * skkt * th) + align256(sizeof(double) * B * th * th) +
-         2 * align256(sizeof(double) * B * skkt) + 2 * cols + cws;
+  return align256(sizeof(double) * B * theta_j_scalars(p)) + align256(sizeof(double) * B * skkt * th) +
+         align256(sizeof(double) * B * th * th) + 2 * align256(sizeof(double) * B * skkt) + 2 * cols + cws;
 }
 
 int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const double *d_theta, const double *d_w,
@@ -909,6 +950,36 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
   int rc = sip_kkt_factor(p, d_model, d_w, t.rhs_sw, d_r2, d_r3, d_work, d_status, stream);
   if (rc != SIP_LQR_OK)
     return rc;
+  if (p->chain_theta) {
+    // the fused passes of kkt_theta_chain_kernels.hpp: right-hand sides of all columns straight from the theta
+    // arena, one multi-rhs Riccati solve, multipliers of all columns + the stage shares of the Schur complement,
+    // their sum and its LLT
+    const Regions r = regions(p, d_work);
+    const long colJ = (long)p->batch * skkt, colV = (long)p->batch * p->in1_len;
+    double *s_part = t.J;
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::theta_rhs_chain_kernel<decltype(fn)::value, decltype(fm)::value>),
+                         dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_theta_rhs, s, p->ck, p->ct, d_model, d_theta,
+                         (const double *)r.inv, t.vecs_cols, colV, (const int32_t *)d_status, (long)p->batch);
+    });
+    if ((e = hipGetLastError()) != hipSuccess)
+      return report(e, "sip_kkt_factor_theta(rhs)");
+    rc = sip_lqr_solve_multi(p->chain, r.in0, t.vecs_cols, t.lsol_cols, th, r.gain, r.lqr, t.cws, s);
+    if (rc != SIP_LQR_OK)
+      return rc;
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::theta_recover_chain_kernel<decltype(fn)::value, decltype(fm)::value>),
+                         dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_theta_recover, s, p->ck, p->ct, d_model,
+                         d_theta, (const double *)r.inv, (const double *)t.lsol_cols, colV, t.KJ, colJ, s_part,
+                         (const int32_t *)d_status, (long)p->batch);
+    });
+    if ((e = hipGetLastError()) != hipSuccess)
+      return report(e, "sip_kkt_factor_theta(recover)");
+    hipLaunchKernelGGL(sipamd::kkt::theta_schur_reduce_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
+                       sizeof(double) * (size_t)th * th, s, p->N, th, sx, d_r1, (const double *)s_part, t.S, d_status,
+                       (long)p->batch, (int)SIP_KKT_THETA_SCHUR_FAILURE);
+    return report(hipGetLastError(), "sip_kkt_factor_theta(schur)");
+  }
   hipLaunchKernelGGL(sipamd::kkt::theta_jacobian_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB), 0, s, p->meta,
                      p->theta_meta, d_theta, t.J, (long)p->batch);
   if ((e = hipGetLastError()) != hipSuccess)
@@ -1001,6 +1072,19 @@ int sip_kkt_solve_theta(const sip_kkt_plan *p, const double *d_model, const doub
   const int rc = sip_kkt_solve(p, d_model, t.rhs_sw, t.sol_sw, d_work, d_status, stream);
   if (rc != SIP_LQR_OK)
     return rc;
+  if (p->chain_theta) {
+    double *d_part = t.J + (size_t)p->batch * p->N * th * th; // behind the Schur partials (kept: solve after solve)
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::theta_dot_chain_kernel<decltype(fn)::value, decltype(fm)::value>),
+                         dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_theta_dot, s, p->ck, p->ct, d_theta,
+                         (const double *)t.sol_sw, d_part, d_status, (long)p->batch);
+    });
+    hipLaunchKernelGGL(sipamd::kkt::theta_finish_parts_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
+                       sizeof(double) * (size_t)th, s, p->N, th, sx, skkt, d_b, (const double *)d_part,
+                       (const double *)t.KJ, (const double *)t.S, (const double *)t.sol_sw, d_sol, d_status,
+                       (long)p->batch);
+    return report(hipGetLastError(), "sip_kkt_solve_theta(finish)");
+  }
   hipLaunchKernelGGL(sipamd::kkt::theta_finish_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB),
                      sizeof(double) * (size_t)th, s, p->meta, p->theta_meta, d_b, t.J, t.KJ, t.S, t.sol_sw, d_sol,
                      d_status, (long)p->batch);

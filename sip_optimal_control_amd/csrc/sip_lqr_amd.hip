@@ -90,6 +90,8 @@ const KernelEntry kKernels[] = {
     MT16_ENTRY(SIP_LQR_F32, float, "f32", 8), MF32(8),
 #elif defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_DIRECT)
     QW16_STAGED(14, 8), QW16_STAGED(15, 4), QW16_STAGED(13, 5), QW16_STAGED(12, 8), QW16_STAGED(14, 4), QW16_STAGED(12, 6),
+#elif defined(SIP_QW16_QUICK) && defined(SIP_QW16_QUICK_MR) // ... with its multi-right-hand-side solve
+    QW16_STAGED_MR(12, 4),
 #elif defined(SIP_QW16_QUICK)
     QW16_STAGED(12, 4),
 #else
