@@ -144,6 +144,11 @@ __device__ __forceinline__ void stage_copy_three(double *d0, const double *__res
   }
 }
 
+// (A software-pipelined walk of these stage kernels -- several consecutive items per wavefront, the next item's
+// loads in flight in registers during the current item's sums, as condense_chain_pipe_kernel does -- was measured
+// and is not here: at (12, 4), p = 8 it took 485 / 926 us for the rhs / recover kernel against 447 / 622 us for one
+// item per workgroup; the prefetch registers (178 VGPRs) cost more occupancy than the overlap returns.)
+
 // what every stage kernel below starts with
 struct ThetaStageCtx {
   long p;

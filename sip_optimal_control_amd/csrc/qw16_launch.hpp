@@ -30,7 +30,7 @@ typedef hipError_t (*launch_mrhs_t)(long batch, int T, const void *mats, const v
                                     const int32_t *status, int ncols, long col_stride, hipStream_t stream);
 constexpr int kMrhsColumns = 8; // columns one multi-rhs launch carries
 #ifndef SIP_MRHS_GROUP
-#define SIP_MRHS_GROUP 4
+#define SIP_MRHS_GROUP 8 // (measured at (12, 4), 8 columns: groups of 8 / 4 / 2 -> 0.69 / 0.94 / 1.3 ms: the sweep is bandwidth-bound, smaller groups re-fetch the operands)
 #endif
 constexpr int kMrhsGroup = SIP_MRHS_GROUP; // ... of which one wavefront carries this many (chain_mrhs.hpp)
 

@@ -900,6 +900,8 @@ int sip_kkt_plan_set_theta(sip_kkt_plan *p, int theta_dim) {
     const char *fe = std::getenv("SIP_KKT_THETA_FUSED");
     p->chain_theta = as_assumed && std::max(p->lds_theta_rhs, p->lds_theta_recover) <= 64 * 1024 &&
                      !(fe != nullptr && fe[0] == '0');
+    if (p->chain_theta)
+      p->name += " + fused theta passes";
   }
   for (int b = 0; b < TH_NUM_BLOCKS; ++b)
     p->theta_meta.to[b] = (const long *)p->d_theta_longs + where[b];

@@ -50,6 +50,7 @@ class BatchedNewtonKKT:
         if self.theta_dim > 0:  # global variables: x = [stagewise x | theta]
             _check(self._lib.sip_kkt_plan_set_theta(h, self.theta_dim), "sip_kkt_plan_set_theta")
             self.theta_len = self._lib.sip_kkt_theta_len(h)
+            self.kernel_name = self._lib.sip_kkt_kernel_name(h).decode()  # (says which theta passes the plan runs)
             self.theta_work = torch.empty(max(1, self._lib.sip_kkt_theta_work_bytes(h)), dtype=torch.uint8,
                                           device=self.device)
         self.full_dim = self.kkt_dim + self.theta_dim

@@ -371,6 +371,52 @@ def test_theta_on_benchmark_chains(n, m, T, p):
         assert np.abs(sol[q] - ref).max() <= 1e-8 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("case", ["family", "odd", "one_edge", "wide_theta"])
+def test_fused_theta_passes_equal_the_generic_ones(monkeypatch, case):
+    """Uniform chains run the theta Schur complement in fused passes (kkt_theta_chain_kernels.hpp: J_theta is read
+    from the theta arena where it is needed and never assembled; the Schur complement is summed from stage partials).
+    Same results as the generic passes (J_theta in memory) to rounding and as the oracle to 1e-8; a failed problem
+    keeps its status and its solution untouched."""
+    if case == "family":
+        base = rk.newton_kkt_dims(8, 3, 7)
+        kw = dict(node_c=base.ncd, node_g=base.ngd, edge_c=base.ecd, edge_g=base.egd)
+        sd, cd, T, p = base.sd, base.cd, 7, 8
+    elif case == "odd":  # interior-node constraints, odd dimensions, odd p: the unaligned copy paths
+        T, p = 5, 3
+        sd, cd = [5] * (T + 1), [3] * T
+        kw = dict(node_c=[1] * T + [2], node_g=[3] * T + [0], edge_c=[3] * T, edge_g=[1] * T)
+    elif case == "one_edge":
+        T, p = 1, 2
+        sd, cd = [4] * 2, [2]
+        kw = dict(node_c=[2, 1], node_g=[0, 2], edge_c=[1], edge_g=[2])
+    else:  # more columns than one multi-rhs launch carries, more (a, b) pairs than lanes
+        T, p = 4, 11
+        sd, cd = [6] * (T + 1), [2] * T
+        kw = dict(node_c=[0] * T + [3], node_g=[0] * T + [4], edge_c=[3] * T, edge_g=[4] * T)
+    dims = rk.KKTDims(list(range(T)), list(range(1, T + 1)), sd, cd, theta_dim=p, **kw)
+    batch = 5
+    model, w, r1, r2, r3, rhs, theta_model = rk.newton_kkt_problem(dims, seed=11, batch=batch, r2_max=1e2)
+    theta_model[2] = rk.initialize_theta_model(dims, -50.0)  # an indefinite Schur complement: status 7
+    d = _dev(model, theta_model, w, r1, r2, r3, rhs)
+    got = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SIP_KKT_THETA_FUSED", fused)
+        kkt = _make(dims, batch)
+        assert ("fused theta passes" in kkt.kernel_name) == (fused == "1")
+        st = kkt.factor_theta(*d[:6]).cpu().tolist()
+        assert st == [0, 0, 7, 0, 0]
+        sentinel = torch.full((batch, dims.full_dim), 3.0, dtype=torch.float64, device="cuda")
+        got[fused] = kkt.solve_theta(d[0], d[1], d[6], sol=sentinel).cpu().numpy()
+        assert (got[fused][2] == 3.0).all()
+    scale = np.abs(got["0"]).max(axis=1, keepdims=True)
+    assert (np.abs(got["1"] - got["0"]) / scale).max() <= 1e-11
+    o = KKTOracle(dims)
+    for q in (0, 1, 3, 4):
+        assert o.factor_theta(model[q], theta_model[q], w[q], r1[q], r2[q], r3[q]) == 0
+        ref = o.solve_theta(model[q], theta_model[q], rhs[q])
+        assert np.abs(got["1"][q] - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
 def test_full_size_properties():
     """Batch 4096 at the f1 benchmark shape (n=12, m=4, T=50, c=6, g=8): size-independent
     properties instead of an oracle pass -- K * sol == rhs through the GPU operator, linearity of
