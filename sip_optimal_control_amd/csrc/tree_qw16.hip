@@ -31,3 +31,13 @@ const TreeClass *find_tree_class(int max_n, int max_m) {
 }
 
 } // namespace sipamd
+
+#ifdef SIP_TREE_STAMPS
+// diagnostic build: read (and clear) the per-segment cycle sums of tree_factor_solve_qw16 (tools/tree_stamps.py)
+extern "C" void sip_lqr_tree_debug_segments(unsigned long long *out8) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sipamd::g_tree_seg), 8 * sizeof(unsigned long long));
+  unsigned long long zero[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(sipamd::g_tree_seg), zero, sizeof(zero));
+}
+#endif

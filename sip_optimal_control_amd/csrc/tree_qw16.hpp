@@ -71,6 +71,25 @@ struct TreeSchedule { // device tables + sizes
   long in_len, out_len, ws_len;
 };
 
+#ifdef SIP_TREE_STAMPS // diagnostic build (tools/tree_ab_build.sh ... -DSIP_TREE_STAMPS): cycles per segment, summed over wavefronts
+__device__ unsigned long long g_tree_seg[8];
+#define TREE_SEG(k)                                                                                  \
+  do {                                                                                               \
+    unsigned long long now_;                                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                     \
+    seg[k] += now_ - seg_last;                                                                       \
+    seg_last = now_;                                                                                 \
+  } while (0)
+#define TREE_SEG_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define TREE_SEG(k)                                                                                  \
+  do {                                                                                               \
+  } while (0)
+#define TREE_SEG_DRAIN()                                                                             \
+  do {                                                                                               \
+  } while (0)
+#endif
+
 template <int N, int M>
 struct TreeLayout {
   static constexpr int GAIN = M * N + M;   // K (M x N, padded) | k
@@ -121,14 +140,21 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
     const double *colp = b + (long)(any ? rows : 0) * cc;
     sfor<0, N>([&](auto ii) {
       constexpr int r = decltype(ii)::value;
-      const double ld = colp[(any && r < rows) ? r : 0];
-      dst[r] = (use && r < rows) ? ld : fill[r];
+      // (both arms of every selection below are plain locals and the conditions are combined with `&`: the
+      // front end then emits a select at once.  With an array element or a short-circuit `&&` in the ternary it
+      // emits a branch diamond first, the optimizer sinks the load into the taken arm, and the "unconditional"
+      // load comes out as an exec-masked region of its own -- 42 of them per backward step before this.)
+      const double ld = colp[(any & (r < rows)) ? r : 0];
+      const double fl = fill[r];
+      const bool take = use & (r < rows);
+      dst[r] = take ? ld : fl;
     });
   };
   // element `idx` of a vector of `len` entries, `fill` past its end or when !on
   auto load_elem = [&](const double *vec, const int len, const int idx, const bool on, const double fill) {
-    const double ld = (len > 0 ? vec : in)[(len > 0 && idx < len) ? idx : 0];
-    return (on && idx < len) ? ld : fill;
+    const double ld = (len > 0 ? vec : in)[((len > 0) & (idx < len)) ? idx : 0];
+    const bool take = on & (idx < len);
+    return take ? ld : fill;
   };
 
   // L2 prefetch of a span of `len` scalars at `span` (this row's problem): every lane pulls one
@@ -185,10 +211,12 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
       const double *rv = anyR ? in + st.orr : in;
       sfor<0, M>([&](auto jj) {
         constexpr int q = decltype(jj)::value;
-        const int qq = (anyR && q < m) ? q : 0;
+        const int qq = (anyR & (q < m)) ? q : 0;
         const double rl = Rc[qq], ml = Mr[(long)(anyM ? n : 0) * qq], rr_ = rv[qq];
-        o.g[q] = (q < m && c < m) ? rl : ((q == c) ? 1.0 : 0.0);
-        o.h[q] = (q < m) ? (isV ? rr_ : (c < n ? ml : 0.0)) : 0.0;
+        const double unit = (q == c) ? 1.0 : 0.0, mz = (c < n) ? ml : 0.0, hv = isV ? rr_ : mz;
+        const bool inR = (q < m) & (c < m);
+        o.g[q] = inR ? rl : unit;
+        o.h[q] = (q < m) ? hv : 0.0;
       });
       load_col(o.a, in + st.oA, nc, n, c, isM, ZERO); // column c of A (nc x n)
       load_col(o.b, in + st.oB, nc, m, c, true, ZERO); // column c of B (nc x m)
@@ -221,8 +249,9 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
           constexpr int r = decltype(ii)::value;
           Sc[r] = slot[cmN * N + r];
           scale[r] = 0.0;
-          Aaug[r] = isV ? slot[N * N + 2 * N + r] : pre.a[r];
-          F[r] = isV ? slot[N * N + 3 * N + r] : 0.0;
+          const double tl = slot[N * N + 2 * N + r], vl = slot[N * N + 3 * N + r], al = pre.a[r]; // (locals: see load_col)
+          Aaug[r] = isV ? tl : al;
+          F[r] = isV ? vl : 0.0;
         });
         spread<N, false, true>(scale, sdi, sdi); // sdi_r sdi_c
         sfor<0, N>([&](auto ii) {
@@ -356,11 +385,20 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
   // slot with the step's other inputs (+40 registers: 0.84 against 0.78).  The register-free L2 prefetch
   // below does: 0.835 -> 0.775 ms there, 0.96 -> 0.89 / 0.925 -> 0.86 ms on the two trees.)
   // (the record of step s + 1 is read during step s: its scalar loads are not waited for at the top of a step)
+#ifdef SIP_TREE_STAMPS
+  // segments: 0 step record + issue of the fetch | 1 wait for the fetched blocks | 2 prefetch issue | 3 edge step
+  // arithmetic (live child) | 4 edge step (child from the spill) | 5 node step | 6 rollout: loads | 7 rollout: arithmetic
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seg_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_last)::"memory");
+#endif
   TreeStep nx = ts.backward[0];
   for (int s = 0; s < ts.n_backward; ++s) {
     const TreeStep st = kPrefetch ? nx : ts.backward[s];
     Pre pre;
     fetch(st, pre);
+    TREE_SEG(0);
+    TREE_SEG_DRAIN();
+    TREE_SEG(1);
     if (kPrefetch && s + 1 < ts.n_backward) { // the read-only inputs of the next step, on their way to L2 meanwhile
       nx = ts.backward[s + 1];
       if (nx.kind == 0)
@@ -373,7 +411,11 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
       if (nx.kind == 0 && !(nx.flags & TS_CHILD_LIVE))
         prefetch(pw + (long)nx.child * L::WS, L::WS, GW{});
     }
+    TREE_SEG(2);
     backward_step(st, pre);
+#ifdef SIP_TREE_STAMPS
+    TREE_SEG(st.kind == 1 ? 5 : (st.flags & TS_CHILD_LIVE) ? 3 : 4);
+#endif
   }
   // root (the last node step): g = v + W (c - delta o v)  (lqr.cpp:798-819)
   {
@@ -404,60 +446,64 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
     }
     xlast = c < n ? x0 : 0.0;
   }
-  if (ts.n_forward > 0)
-    nx = ts.forward[0];
-  for (int s = 0; s < ts.n_forward; ++s) {
-    const TreeStep st = kPrefetch ? nx : ts.forward[s];
-    const int e = st.edge, n = st.n, nc = st.nc, m = st.m;
-    if (kPrefetch && s + 1 < ts.n_forward) { // A | B, gains, spill slot and delta of the next edge / child
-      nx = ts.forward[s + 1];
-      prefetch(in + nx.oA, (long)nx.nc * (nx.n + nx.m), G2{});
-      prefetch(pg + (long)nx.edge * L::GAIN, L::GAIN, G1{});
-      prefetch(pw + (long)nx.child * L::WS, L::WS, GW{});
-      prefetch(in + nx.odc, nx.nc, G1{});
-    }
-    double x;
-    if (st.flags & TS_CHILD_LIVE) {
-      x = xlast;
-    } else {
-      const double xl = out[(c < n) ? st.oxp + c : 0]; // written by this lane when the parent was rolled out
-      x = (c < n) ? xl : 0.0;                           // (out_len > 0 is guaranteed by the host)
-    }
-    const double *gi = pg + (long)e * L::GAIN;
+  // The operands of a rollout step depend on the step record only, not on x: they are requested ONE STEP AHEAD
+  // into a second register set (two sets alternate, the loop runs two steps per trip), while the blocks of the
+  // step after that are on their way to L2 (prefetch) and the record of the one after that is being read.  With
+  // the loads at the top of the step they serve, the rollout ran at one exposed round trip per step: 37 % of the
+  // kernel's cycles for 2 % of arithmetic (tools/tree_stamps.py).
+  struct Fwd {
+    double KT[N], Arow[N], Brow[M], Wc[N], kk0, gg, hh, dd, xp;
+  };
+  auto load_fwd = [&](const TreeStep &st, Fwd &o) {
+    const int n = st.n, nc = st.nc, m = st.m;
+    const double *gi = pg + (long)st.edge * L::GAIN;
     const double *slot = pw + (long)st.child * L::WS;
-    double KT[N], Arow[N], Brow[M], Wc[N];
-    {
-      const bool anyA = nc > 0 && n > 0, anyB = nc > 0 && m > 0;
-      const double *Ar = (anyA ? in + st.oA : in) + (anyA && c < nc ? c : 0); // row c of A (nc x n)
-      const double *Br = (anyB ? in + st.oB : in) + (anyB && c < nc ? c : 0); // row c of B (nc x m)
-      sfor<0, N>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        KT[k] = gi[k * M + cuM];   // padded gains: zeros on the padding
-        Wc[k] = slot[cmN * N + k]; // S symmetric: row c = column c
-        const double al = Ar[(long)(anyA ? nc : 0) * ((anyA && k < n) ? k : 0)];
-        Arow[k] = (k < n && c < nc) ? al : 0.0;
-      });
-      sfor<0, M>([&](auto jj) {
-        constexpr int q = decltype(jj)::value;
-        const double bl = Br[(long)(anyB ? nc : 0) * ((anyB && q < m) ? q : 0)];
-        Brow[q] = (q < m && c < nc) ? bl : 0.0;
-      });
-    }
-    const double kk0 = gi[N * M + cuM], gg = slot[N * N + cmN], hh = slot[N * N + N + cmN];
-    const double dd = load_elem(in + st.odc, nc, c, true, 1.0);
-    const double sdi = rsqrt_nr(dd), sdv = dd * sdi;
-    double acc[4] = {kk0, 0.0, 0.0, 0.0};
-    dotv<N, true>(acc, x, KT);
+    const bool anyA = nc > 0 && n > 0, anyB = nc > 0 && m > 0;
+    const double *Ar = (anyA ? in + st.oA : in) + (anyA && c < nc ? c : 0); // row c of A (nc x n)
+    const double *Br = (anyB ? in + st.oB : in) + (anyB && c < nc ? c : 0); // row c of B (nc x m)
+    sfor<0, N>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      o.KT[k] = gi[k * M + cuM];   // padded gains: zeros on the padding
+      o.Wc[k] = slot[cmN * N + k]; // S symmetric: row c = column c
+      const double al = Ar[(long)(anyA ? nc : 0) * ((anyA & (k < n)) ? k : 0)];
+      const bool inA = (k < n) & (c < nc);
+      o.Arow[k] = inA ? al : 0.0;
+    });
+    sfor<0, M>([&](auto jj) {
+      constexpr int q = decltype(jj)::value;
+      const double bl = Br[(long)(anyB ? nc : 0) * ((anyB & (q < m)) ? q : 0)];
+      const bool inB = (q < m) & (c < nc);
+      o.Brow[q] = inB ? bl : 0.0;
+    });
+    o.kk0 = gi[N * M + cuM], o.gg = slot[N * N + cmN], o.hh = slot[N * N + N + cmN];
+    o.dd = load_elem(in + st.odc, nc, c, true, 1.0);
+    // x of the parent as this lane wrote it when the parent was rolled out (at least two steps ago unless the step
+    // is TS_CHILD_LIVE, which takes x from the previous step's registers and ignores this)
+    const double xl = out[(c < n) ? st.oxp + c : 0]; // (out_len > 0 is guaranteed by the host)
+    o.xp = (c < n) ? xl : 0.0;
+  };
+  auto prefetch_fwd = [&](const TreeStep &st) { // A | B, gains, spill slot and delta of an edge / its child
+    prefetch(in + st.oA, (long)st.nc * (st.n + st.m), G2{});
+    prefetch(pg + (long)st.edge * L::GAIN, L::GAIN, G1{});
+    prefetch(pw + (long)st.child * L::WS, L::WS, GW{});
+    prefetch(in + st.odc, st.nc, G1{});
+  };
+  auto forward_step = [&](const TreeStep &st, const Fwd &f) {
+    const int nc = st.nc, m = st.m;
+    const double x = (st.flags & TS_CHILD_LIVE) ? xlast : f.xp;
+    const double sdi = rsqrt_nr(f.dd), sdv = f.dd * sdi;
+    double acc[4] = {f.kk0, 0.0, 0.0, 0.0};
+    dotv<N, true>(acc, x, f.KT);
     const double u = sum4(acc); // u = k + K x  (lqr.cpp:856-857)
     double az[4] = {0.0, 0.0, 0.0, 0.0};
-    dotv<N, true>(az, x, Arow);
-    dotv<M, true>(az, u, Brow);
+    dotv<N, true>(az, x, f.Arow);
+    dotv<M, true>(az, u, f.Brow);
     const double zeta = sum4(az) * sdi; // D^{-1/2} (A x + B u)
     double as[4] = {0.0, 0.0, 0.0, 0.0};
-    dotv<N, true>(as, zeta, Wc);
+    dotv<N, true>(as, zeta, f.Wc);
     const double sz = sum4(as);
-    const double xc = sdv * (sz + hh);                   // x_c = D^{1/2} (S zeta + h)
-    const double yc = __builtin_fma(sdi, zeta - sz, gg); // y_c = g_c + D^{-1/2} (zeta - S zeta)
+    const double xc = sdv * (sz + f.hh);                   // x_c = D^{1/2} (S zeta + h)
+    const double yc = __builtin_fma(sdi, zeta - sz, f.gg); // y_c = g_c + D^{-1/2} (zeta - S zeta)
     if (valid) {
       if (c < m)
         out[st.ou + c] = u;
@@ -467,7 +513,41 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
       }
     }
     xlast = c < nc ? xc : 0.0;
+  };
+  const int nf = ts.n_forward;
+  auto record = [&](const int s) { return ts.forward[s < nf ? s : nf - 1]; };
+  if (nf > 0) {
+    TreeStep r0 = record(0), r1 = record(1), r2 = record(2);
+    Fwd fa, fb;
+    load_fwd(r0, fa);
+    for (int s = 0; s < nf; s += 2) {
+      // step s on set a; r0, r1, r2 = the records of steps s, s + 1, s + 2
+      const TreeStep r3 = record(s + 3);
+      if (s + 1 < nf)
+        load_fwd(r1, fb);
+      if (kPrefetch && s + 2 < nf)
+        prefetch_fwd(r2);
+      TREE_SEG(6);
+      forward_step(r0, fa);
+      TREE_SEG(7);
+      if (s + 1 < nf) { // step s + 1 on set b
+        const TreeStep r4 = record(s + 4);
+        if (s + 2 < nf)
+          load_fwd(r2, fa);
+        if (kPrefetch && s + 3 < nf)
+          prefetch_fwd(r3);
+        TREE_SEG(6);
+        forward_step(r1, fb);
+        TREE_SEG(7);
+        r0 = r2, r1 = r3, r2 = r4;
+      }
+    }
   }
+#ifdef SIP_TREE_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k)
+      atomicAdd(&g_tree_seg[k], seg[k]);
+#endif
 }
 
 } // namespace sipamd
