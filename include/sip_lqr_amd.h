@@ -187,8 +187,10 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
  * 16-byte aligned bases and strides; 3 * ab_problem_stride * 8 + (n*n + n*m) * 8 < 2^32 bytes (the four
  * problems of a wavefront are addressed by 32-bit offsets; SIP_LQR_ERR_INVALID_ARGUMENT beyond: that is
  * a problem stride of up to ~178 M scalars).  Available (sip_lqr_has_split() == 1) for fp64 plans whose fused
- * kernel is an LDS-staged one of the reference's Newton-KKT benchmark grid (n in {4, 6, 8, 12},
- * m in {1, 2, 3, 4}); SIP_LQR_ERR_UNSUPPORTED otherwise.  Everything else as sip_lqr_factor_solve. */
+ * kernel is an LDS-staged one (n <= 15, m <= 8) and whose A | B block is a whole number of 16-byte pieces
+ * (n (n + m) even: 88 of those 120 shapes, the reference's Newton-KKT benchmark grid among them; with n (n + m)
+ * odd the blocks of every other stage would start on an odd 8-byte offset); SIP_LQR_ERR_UNSUPPORTED otherwise.
+ * Everything else as sip_lqr_factor_solve. */
 int sip_lqr_has_split(const sip_lqr_plan *plan);
 int64_t sip_lqr_split_mats_len(const sip_lqr_plan *plan);
 int sip_lqr_factor_solve_split(const sip_lqr_plan *plan, const void *d_mats, const void *d_ab,

@@ -379,6 +379,9 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
       asm volatile("" ::: "memory");
     }
   };
+  // (Round 3, after the loads became selects: a non-live child's S column, t and v requested at the top of the step
+  // with the other inputs instead of inside the step -- 0.82 / 0.93 / 0.85 ms against 0.57 / 0.66 / 0.61: the 27 extra
+  // live values spill.)
   // (Requesting the blocks of step s + 1 into a second REGISTER set before the arithmetic of step s did
   // not pay -- 0.87 against 0.84 ms on the heterogeneous chain of the reference's benchmark family: the
   // kernel is at 256 VGPRs + AGPR copies already -- and neither did requesting a non-live child's spill

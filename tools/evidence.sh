@@ -20,6 +20,7 @@ timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c4 --workload c4 > $OUT/prof_c4.lo
 timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c2 --workload c2 > $OUT/prof_c2.log 2>&1
 timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c3full --workload c3 --layout full > $OUT/prof_c3full.log 2>&1
 timeout -k 10 300 tools/profile_kkt.sh ${TAG}_kkt > $OUT/prof_kkt.log 2>&1
+timeout -k 10 300 tools/profile_kkt.sh ${TAG}_theta8 --theta 8 > $OUT/prof_theta8.log 2>&1
 timeout -k 10 120 python bench.py --workload c4 --steps 10 --no-cpu-baseline > $OUT/bench_c4_again.json 2>/dev/null
 ( timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --blocks 2 > $OUT/bench_g2_rehearsal.json 2> $OUT/bench_g2_rehearsal.err ) || echo "2-rank rehearsal failed"
 # counters that could separate DRAM from Infinity-Cache traffic (MI355X_MICROARCH.md: FETCH_SIZE counts fabric requests)
