@@ -149,6 +149,11 @@ __device__ __forceinline__ void stage_copy_three(double *d0, const double *__res
 // and is not here: at (12, 4), p = 8 it took 485 / 926 us for the rhs / recover kernel against 447 / 622 us for one
 // item per workgroup; the prefetch registers (178 VGPRs) cost more occupancy than the overlap returns.)
 
+// (Nor are they issue-bound: with theta_dim a template parameter as well (p = 4, 8 of the reference's theta benchmarks)
+// and the scalar fallback of the stage copies compiled out, the static instruction count of the rhs / recover kernels
+// halved -- 2 354 -> 1 167 and 2 298 -> 1 174 -- and `factor_theta` did not move (2.45 ms): they run at 4.2 / 4.9 TB/s
+// of mostly 16-byte-per-lane traffic.  Not kept.)
+
 // what every stage kernel below starts with
 struct ThetaStageCtx {
   long p;
