@@ -379,6 +379,10 @@ __global__ __launch_bounds__(64) void tree_factor_solve_qw16(
       asm volatile("" ::: "memory");
     }
   };
+  // (Round 3: the blocks of a step loaded COALESCED -- lane c: elements c, c + 16, ... of the contiguous block -- parked in
+  // a per-problem LDS region and the lanes' columns read from there, instead of 40-60 per-lane column loads that touch a
+  // different cache line in almost every lane: 0.65 / 0.66 / 0.65 ms against 0.58 / 0.66 / 0.62.  The column loads hit
+  // in the vector L1 and were not what the top of a step costs; the LDS round trip is added latency.)
   // (Round 3, after the loads became selects: a non-live child's S column, t and v requested at the top of the step
   // with the other inputs instead of inside the step -- 0.82 / 0.93 / 0.85 ms against 0.57 / 0.66 / 0.61: the 27 extra
   // live values spill.)

@@ -371,7 +371,7 @@ def test_theta_on_benchmark_chains(n, m, T, p):
         assert np.abs(sol[q] - ref).max() <= 1e-8 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("case", ["family", "odd", "one_edge", "wide_theta"])
+@pytest.mark.parametrize("case", ["family", "odd", "one_edge", "wide_theta", "many_columns"])
 def test_fused_theta_passes_equal_the_generic_ones(monkeypatch, case):
     """Uniform chains run the theta Schur complement in fused passes (kkt_theta_chain_kernels.hpp: J_theta is read
     from the theta arena where it is needed and never assembled; the Schur complement is summed from stage partials).
@@ -389,6 +389,10 @@ def test_fused_theta_passes_equal_the_generic_ones(monkeypatch, case):
         T, p = 1, 2
         sd, cd = [4] * 2, [2]
         kw = dict(node_c=[2, 1], node_g=[0, 2], edge_c=[1], edge_g=[2])
+    elif case == "many_columns":  # more (column, row) pairs than the lanes prefetch (2 x 64): the tail loops
+        T, p = 3, 20
+        sd, cd = [6] * (T + 1), [2] * T
+        kw = dict(node_c=[1] * T + [3], node_g=[2] * T + [4], edge_c=[3] * T, edge_g=[4] * T)
     else:  # more columns than one multi-rhs launch carries, more (a, b) pairs than lanes
         T, p = 4, 11
         sd, cd = [6] * (T + 1), [2] * T
