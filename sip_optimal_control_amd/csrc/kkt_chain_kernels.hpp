@@ -823,11 +823,13 @@ recover_chain_kernel(const ChainKkt ck_in, const double *__restrict__ model_all,
 // rows of stage i, the dynamics rows of node i + 1 (plus the root's at i = 0) and the constraint
 // rows of node i and edge i: everything they touch is in stage i's model item (staged in LDS) and
 // in a few slices of x.  x-space vectors are [x | theta (th entries)].
+template <int FN = 0, int FM = 0>
 __global__ void __launch_bounds__(TPB)
-apply_chain_kernel(const ChainKkt ck, const int th, const double *__restrict__ model_all,
+apply_chain_kernel(const ChainKkt ck_in, const int th, const double *__restrict__ model_all,
                    const double *__restrict__ w_all, const double *__restrict__ r1_all,
                    const double *__restrict__ r2_all, const double *__restrict__ r3_all, const ApplyIO io,
                    long batch) {
+  const ChainKkt ck = family_dims<FN, FM>(ck_in);
   extern __shared__ double sm[];
   const int n = ck.n, m = ck.m, T = ck.T;
   const long p = blockIdx.x / (T + 1);

@@ -297,8 +297,11 @@ int apply_blocks(const sip_kkt_plan *p, const double *d_model, const double *d_t
     return report(on_device.err, what);
   const int th = d_theta != nullptr ? p->theta_dim : 0;
   if (p->chain_kernels) {
-    hipLaunchKernelGGL(sipamd::kkt::apply_chain_kernel, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_apply, s, p->ck, th, d_model, d_w, d_r1, d_r2, d_r3, io, (long)p->batch);
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::apply_chain_kernel<decltype(fn)::value, decltype(fm)::value>), dim3(node_grid(p)),
+                         dim3(sipamd::kkt::TPB), p->lds_chain_apply, s, p->ck, th, d_model, d_w, d_r1, d_r2, d_r3, io,
+                         (long)p->batch);
+    });
   } else {
     sipamd::kkt::Meta wide = p->meta; // x-space = [stagewise x | theta]
     wide.theta_dim = th;

@@ -107,6 +107,8 @@ def main():
     # residual through the GPU operator (the benchmark's residual_norm counter, :110-124)
     prod = kkt.add_Kx_to_y(*data[:5], sol)
     res = float((prod - data[5]).norm(dim=1).max())
+    # ... and its own rate: y += K x, the loop body of BM_NewtonKKTResidual (newton_kkt_benchmark.cpp:417-441)
+    ms_apply = _time(lambda: kkt.add_Kx_to_y(*data[:5], sol, y=prod), max(5, args.steps // 2))
     alg_bytes = 8 * (kkt.model_len + 2 * kkt.z_dim + kkt.x_dim + kkt.y_dim + 2 * kkt.kkt_dim)
     out = {
         "metric": "newton_kkt_factor_solves_per_sec", "value": batch / (ms * 1e-3), "unit": "solves/s",
@@ -114,6 +116,7 @@ def main():
         "config": {"workload": f"NewtonKKTProblem(n={n}, m={m}, T={T}), c={c}, g={g}, batch {batch}",
                    "riccati": kkt.kernel_name},
         "max_residual_norm": res,
+        "ms_add_Kx_to_y": ms_apply, "Kx_per_sec": batch / (ms_apply * 1e-3),
         "roofline": {"bound": "hbm", "achieved": batch * alg_bytes / (ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": batch * alg_bytes / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None},
         "algorithmic_bytes_per_solve": alg_bytes,
