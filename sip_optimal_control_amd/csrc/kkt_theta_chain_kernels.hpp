@@ -480,6 +480,139 @@ theta_dot_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double *
     d_part[(s.p * (ck.T + 1) + s.i) * (long)P + a] = ts.dot(a, vx, vd, vr);
 }
 
+// The theta terms of y += K x, or of the selected blocks of it (ApplyIO::parts: the theta sections of add_Hx / Cx / CTx /
+// Gx / GTx_to_y, helpers.cpp:1023-1066, 1128-1158, 1221-1249, 1285-1308, 1344-1367), for a uniform chain.  The generic
+// kernel (apply_theta_kernel) walks the nodes and edges of a problem one after the other with one wavefront (2.4 ms at
+// the benchmark shape, p = 8, for 0.94 GB of theta arena).  Here a workgroup of W wavefronts owns a problem, wavefront w
+// takes stages w, w + W, ...: it stages the stage's theta item and the stage's slices of x in ITS part of the LDS, adds
+// J_theta theta to the rows the stage owns, and accumulates the stage's share of y_theta = J_theta^T x + H_tt theta in
+// its LDS accumulator; the W accumulators are summed in wavefront order at the end (no scratch memory, no atomics:
+// the result does not depend on scheduling).
+// LDS per wavefront: [theta item | x_i|u_i (n + m) | dynamics rows of node i+1 (n) | constraint rows (lds_rows) |
+//                     theta (p, even) | y_theta accumulator (p, even)]
+template <int FN = 0, int FM = 0>
+__global__ void __launch_bounds__(512)
+apply_theta_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double *__restrict__ theta_all,
+                         const double *__restrict__ r1_all, const ApplyIO io, const long batch) {
+  const ChainKkt ck = family_dims<FN, FM>(ck_in);
+  extern __shared__ double sm[];
+  const long prob = blockIdx.x;
+  if (prob >= batch)
+    return;
+  const int n = ck.n, m = ck.m, T = ck.T, P = ct.p, per = n + m, R = ck.lds_rows, Pe = (P + 1) & ~1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int vlen = (per + n + 1) & ~1;                // x_i|u_i and the dynamics rows, padded to an even length
+  const int wl = ct.lds_item + vlen + R + 2 * Pe;     // doubles per wavefront (even: the items stay 16-byte aligned)
+  double *th = sm + wave * wl, *vx = th + ct.lds_item, *vd = vx + per, *vr = vx + vlen, *tv = vr + R, *yacc = tv + Pe;
+  const int parts = io.parts;
+  const bool pH = parts & AP_H, pC = parts & AP_C, pCT = parts & AP_CT, pG = parts & AP_G, pGT = parts & AP_GT,
+             pR = parts & AP_REG;
+  const int sx = ck.x_dim;
+  const double *x_x = io.x_x ? io.x_x + prob * io.sx : nullptr, *x_y = io.x_y ? io.x_y + prob * io.sy : nullptr;
+  const double *x_z = io.x_z ? io.x_z + prob * io.sz : nullptr;
+  double *y_x = io.y_x ? io.y_x + prob * io.sx : nullptr, *y_y = io.y_y ? io.y_y + prob * io.sy : nullptr;
+  double *y_z = io.y_z ? io.y_z + prob * io.sz : nullptr;
+  const bool use_theta = (pH || pC || pG || pR) && x_x != nullptr; // theta is read by H, C, G (and the r1 term)
+  for (int a = lane; a < P; a += 64) {
+    tv[a] = use_theta ? x_x[sx + a] : 0.0;
+    yacc[a] = 0.0;
+  }
+  for (int i = wave; i <= T; i += waves) {
+    ThetaStageCtx s;
+    {
+      s.p = prob, s.i = i, s.tid = lane, s.last = i == T;
+      s.c = s.last ? ck.cT : ck.cn, s.g = s.last ? ck.gT : ck.gn;
+      s.ce = s.last ? 0 : ck.ce, s.ge = s.last ? 0 : ck.ge;
+      s.nrows = s.c + s.g + s.ce + s.ge;
+      s.item = nullptr, s.yinv = s.zinv = nullptr;
+      s.titem = theta_all + prob * ct.theta_len + (long)i * (ct.node_len + ct.edge_len);
+      s.y_dyn = i * (n + ck.cn), s.y_nc = s.y_dyn + n, s.y_ec = T * (n + ck.cn) + n + ck.cT + i * ck.ce;
+      s.z_n = i * ck.gn, s.z_e = T * ck.gn + ck.gT + i * ck.ge;
+    }
+    const bool last = s.last;
+    const int c = s.c, g = s.g, ce = s.ce, nrows = s.nrows, xl = last ? n : per;
+    // constraint row k of the stage: in the y-space (c rows) or the z-space (g rows), and where
+    auto row_is_y = [&](const int k) { return k < c || (k >= c + g && k < c + g + ce); };
+    auto row_at = [&](const int k) {
+      if (k < c)
+        return s.y_nc + k;
+      if (k < c + g)
+        return s.z_n + (k - c);
+      if (k < c + g + ce)
+        return s.y_ec + (k - c - g);
+      return s.z_e + (k - c - g - ce);
+    };
+    // the stage's slices of x, zero where the selected blocks do not read them
+    for (int e = lane; e < xl; e += 64)
+      vx[e] = pH ? x_x[i * per + e] : 0.0;
+    if (!last)
+      for (int e = lane; e < n; e += 64)
+        vd[e] = pCT ? x_y[s.y_dyn + (n + ck.cn) + e] : 0.0;
+    for (int k = lane; k < nrows; k += 64) {
+      const bool iny = row_is_y(k);
+      vr[k] = iny ? (pCT ? x_y[row_at(k)] : 0.0) : (pGT ? x_z[row_at(k)] : 0.0);
+    }
+    stage_copy2(th, s.titem, theta_item_len(ck, ct, last), lane);
+    const ThetaStage ts = theta_stage(ck, ct, th, last);
+    // rows += J_theta theta
+    if (pH) {
+      for (int j = lane; j < xl; j += 64) {
+        double *dst = y_x + i * per + j;
+        if (j < n) { // the node's block, then the edge's (the order of the node / edge loops of the reference)
+          double an = 0.0, ae = 0.0;
+          for (int a = 0; a < P; ++a)
+            an += ts.NX[j + n * a] * tv[a];
+          if (!last)
+            for (int a = 0; a < P; ++a)
+              ae += ts.EX[j + n * a] * tv[a];
+          *dst = last ? *dst + an : (*dst + an) + ae;
+        } else {
+          double au = 0.0;
+          for (int a = 0; a < P; ++a)
+            au += ts.EU[(j - n) + m * a] * tv[a];
+          *dst += au;
+        }
+      }
+    }
+    if (pC && !last)
+      for (int j = lane; j < n; j += 64) { // dynamics rows of node i + 1
+        double acc = 0.0;
+        for (int a = 0; a < P; ++a)
+          acc += ts.ED[j + n * a] * tv[a];
+        y_y[s.y_dyn + (n + ck.cn) + j] += acc;
+      }
+    if (pC || pG)
+      for (int k = lane; k < nrows; k += 64) {
+        const bool iny = row_is_y(k);
+        if (iny ? !pC : !pG)
+          continue;
+        double acc = 0.0;
+        for (int a = 0; a < P; ++a)
+          acc += ts.row(a, k) * tv[a];
+        (iny ? y_y : y_z)[row_at(k)] += acc;
+      }
+    // y_theta += J_theta^T x (H, CT, GT) + H_theta_theta theta (H)
+    if (pH || pCT || pGT)
+      for (int a = lane; a < P; a += 64) {
+        double acc = ts.dot(a, vx, vd, vr);
+        if (pH)
+          for (int b = 0; b < P; ++b)
+            acc += (last ? ts.NTT[a + P * b] : ts.NTT[a + P * b] + ts.ETT[a + P * b]) * tv[b];
+        yacc[a] += acc;
+      }
+  }
+  __syncthreads();
+  if (wave == 0 && (pH || pCT || pGT || pR) && y_x != nullptr)
+    for (int a = lane; a < P; a += 64) {
+      double acc = 0.0;
+      for (int w = 0; w < waves; ++w)
+        acc += (sm + w * wl + (wl - Pe))[a];
+      if (pR)
+        acc += r1_all[prob * (sx + P) + sx + a] * tv[a];
+      y_x[sx + a] += acc;
+    }
+}
+
 // theta = S^-1 (b_theta - J^T K^-1 b) with J^T K^-1 b from the stage partials; sol = K^-1 b - (K^-1 J) theta,
 // re-inserted as [x | theta | y | z]  (helpers.cpp:920-950).  One workgroup per problem.  LDS: p.
 __global__ void __launch_bounds__(TPB)

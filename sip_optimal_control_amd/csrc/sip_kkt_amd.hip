@@ -308,7 +308,19 @@ int apply_blocks(const sip_kkt_plan *p, const double *d_model, const double *d_t
     hipLaunchKernelGGL(sipamd::kkt::apply_kernel, dim3(item_grid(p)), dim3(sipamd::kkt::TPB), 0, s, wide, d_model,
                        d_w, d_r1, d_r2, d_r3, io, (long)p->batch);
   }
-  if (th > 0)
+  if (th > 0 && p->chain_theta) {
+    // W wavefronts per problem, as many as 64 KiB of LDS hold (kkt_theta_chain_kernels.hpp)
+    const size_t pe = ((size_t)th + 1) & ~(size_t)1;
+    const size_t vlen = ((size_t)(2 * p->ck.n + p->ck.m) + 1) & ~(size_t)1;
+    const size_t per_wave = sizeof(double) * ((size_t)p->ct.lds_item + vlen + p->ck.lds_rows + 2 * pe);
+    int waves = (int)std::min<size_t>(8, (64 * 1024) / per_wave);
+    waves = std::max(1, std::min(waves, p->N));
+    family_dispatch(p->family, [&](auto fn, auto fm) {
+      hipLaunchKernelGGL((sipamd::kkt::apply_theta_chain_kernel<decltype(fn)::value, decltype(fm)::value>),
+                         dim3((unsigned)p->batch), dim3(64 * waves), per_wave * waves, s, p->ck, p->ct, d_theta, d_r1, io,
+                         (long)p->batch);
+    });
+  } else if (th > 0)
     hipLaunchKernelGGL(sipamd::kkt::apply_theta_kernel, dim3((unsigned)p->batch), dim3(sipamd::kkt::TPB), 0, s,
                        p->meta, p->theta_meta, d_theta, d_r1, io, (long)p->batch);
   return report(hipGetLastError(), what);

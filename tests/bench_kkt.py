@@ -56,13 +56,16 @@ def theta_main(args):
     assert int((kkt.status != 0).sum()) == 0
     ms_solve = _time(lambda: kkt.solve_theta(d[0], d[1], d[6], sol=sol), args.steps)
     ms_split0 = _time(lambda: kkt.factor(d[0], d[2], d[3][:, :dims.x_dim].contiguous(), d[4], d[5]), args.steps)
+    yk = torch.zeros(batch, dims.full_dim, dtype=torch.float64, device="cuda")
+    # y += K x with the theta blocks: the loop body of BM_NewtonKKTThetaResidual (newton_kkt_benchmark.cpp:417-441)
+    ms_apply = _time(lambda: kkt.add_Kx_to_y_theta(*d[:6], sol, y=yk), args.steps)
     o = KKTOracle(dims)
     assert o.factor_theta(model[0], theta_model[0], w[0], r1[0], r2[0], r3[0]) == 0
     ref = o.solve_theta(model[0], theta_model[0], rhs[0])
     err = float(np.abs(sol[0].cpu().numpy() - ref).max() / np.abs(ref).max())
     print(json.dumps({"metric": "newton_kkt_theta_factor_and_solve_ms", "theta_dim": p, "batch": batch,
                       "config": f"NewtonKKTProblem(n={n}, m={m}, T={T}, p={p})", "riccati": kkt.kernel_name,
-                      "ms_factor_theta": ms_factor, "ms_solve_theta": ms_solve, "ms_factor_stagewise": ms_split0,
+                      "ms_factor_theta": ms_factor, "ms_solve_theta": ms_solve, "ms_factor_stagewise": ms_split0, "ms_add_Kx_to_y_theta": ms_apply,
                       "factor_theta_per_sec": batch / (ms_factor * 1e-3), "solve_theta_per_sec": batch / (ms_solve * 1e-3),
                       "max_rel_err_vs_oracle": err}))
 

@@ -402,7 +402,7 @@ def test_fused_theta_passes_equal_the_generic_ones(monkeypatch, case):
     model, w, r1, r2, r3, rhs, theta_model = rk.newton_kkt_problem(dims, seed=11, batch=batch, r2_max=1e2)
     theta_model[2] = rk.initialize_theta_model(dims, -50.0)  # an indefinite Schur complement: status 7
     d = _dev(model, theta_model, w, r1, r2, r3, rhs)
-    got = {}
+    got, prods = {}, {}
     for fused in ("1", "0"):
         monkeypatch.setenv("SIP_KKT_THETA_FUSED", fused)
         kkt = _make(dims, batch)
@@ -412,8 +412,16 @@ def test_fused_theta_passes_equal_the_generic_ones(monkeypatch, case):
         sentinel = torch.full((batch, dims.full_dim), 3.0, dtype=torch.float64, device="cuda")
         got[fused] = kkt.solve_theta(d[0], d[1], d[6], sol=sentinel).cpu().numpy()
         assert (got[fused][2] == 3.0).all()
+        # y += K x with the theta blocks (stage-parallel for chains, apply_theta_chain_kernel), all blocks and one by one
+        xs = _dev(np.random.default_rng(5).standard_normal((batch, dims.full_dim)))[0]
+        prods[fused] = [kkt.add_Kx_to_y_theta(*d[:6], xs).cpu().numpy()]
+        for op, (src, dst) in kkt.BLOCK_SPACES.items():
+            xv = _dev(np.random.default_rng(6).standard_normal((batch, kkt.space_dim(src, True))))[0]
+            prods[fused].append(kkt.add_block_to_y(op, d[0], xv, theta_model=d[1]).cpu().numpy())
     scale = np.abs(got["0"]).max(axis=1, keepdims=True)
     assert (np.abs(got["1"] - got["0"]) / scale).max() <= 1e-11
+    for a, b in zip(prods["1"], prods["0"]):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
     o = KKTOracle(dims)
     for q in (0, 1, 3, 4):
         assert o.factor_theta(model[q], theta_model[q], w[q], r1[q], r2[q], r3[q]) == 0
