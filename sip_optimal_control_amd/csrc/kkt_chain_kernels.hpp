@@ -944,7 +944,43 @@ apply_chain_kernel(const ChainKkt ck_in, const int th, const double *__restrict_
     pye = x_y[y_ec + tid];
   if (tid < ge && in_z)
     pze = x_z[z_e + tid];
-  stage_copy2(buf, item, node_len + edge_len, tid);
+  { // only what the selected blocks read travels: the hull of their ranges in the stage image (H: Q and the edge's
+    // Q | M | R; C, CT: dc_dx, A | B, the edge's dc_dx | dc_du; G, GT: the dg blocks) -- SIP is handed the five operators
+    // one by one (sip_optimal_control.cpp:147-190), and each staged the whole 6 KB stage
+    const int total = node_len + edge_len, o_a = node_len + nn + nm + m * m, o_j = o_a + nn + nm;
+    int lo = total, hi = 0;
+    auto need = [&](const int a, const int b) {
+      if (b > a) {
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+      }
+    };
+    if (pH) {
+      need(0, nn);
+      if (!last)
+        need(node_len, o_a);
+    }
+    if (pC || pCT) {
+      need(nn, nn + c * n);
+      if (!last) {
+        need(o_a, o_j);
+        need(o_j, o_j + ce * (n + m));
+      }
+    }
+    if (pG || pGT) {
+      need(nn + c * n, node_len);
+      if (!last)
+        need(o_j + ce * (n + m), total);
+    }
+#ifdef SIP_KKT_APPLY_FULL_STAGE // diagnostic: the whole stage image whatever the mask (tools/kkt_ab_build.sh)
+    lo = 0, hi = total;
+#endif
+    lo &= ~1; // (whole 16-byte pieces where the image allows them)
+    hi = (hi + 1) & ~1;
+    hi = hi < total ? hi : total;
+    if (hi > lo)
+      stage_copy2(buf + lo, item + lo, hi - lo, tid);
+  }
   if (tid < n) {
     vx[tid] = px;
     vd[tid] = pd;
