@@ -542,22 +542,51 @@ apply_theta_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double
         return s.y_ec + (k - c - g);
       return s.z_e + (k - c - g - ce);
     };
-    // the stage's slices of x, zero where the selected blocks do not read them
-    for (int e = lane; e < xl; e += 64)
+    // Every small read of the stage -- the lane's entries of the slices of x, and the present value of the output
+    // rows the lane will update -- is requested before the item's copy: one HBM round trip per stage, not one per
+    // slice and another per read-modify-write.  (Entries past the first 64 of a slice, if any, take the plain path.)
+    const bool yrow = lane < nrows && row_is_y(lane);
+    const int rat = lane < nrows ? row_at(lane) : 0;
+    double r_vx = 0.0, r_vd = 0.0, r_vr = 0.0, o_x = 0.0, o_d = 0.0, o_r = 0.0;
+    if (lane < xl) {
+      if (pH)
+        r_vx = x_x[i * per + lane], o_x = y_x[i * per + lane];
+    }
+    if (!last && lane < n) {
+      if (pCT)
+        r_vd = x_y[s.y_dyn + (n + ck.cn) + lane];
+      if (pC)
+        o_d = y_y[s.y_dyn + (n + ck.cn) + lane];
+    }
+    if (lane < nrows) {
+      if (yrow ? pCT : pGT)
+        r_vr = (yrow ? x_y : x_z)[rat];
+      if (yrow ? pC : pG)
+        o_r = (yrow ? y_y : y_z)[rat];
+    }
+    stage_copy2(th, s.titem, theta_item_len(ck, ct, last), lane);
+    // the stage's slices of x in LDS, zero where the selected blocks do not read them
+    if (lane < xl)
+      vx[lane] = r_vx;
+    if (!last && lane < n)
+      vd[lane] = r_vd;
+    if (lane < nrows)
+      vr[lane] = r_vr;
+    for (int e = lane + 64; e < xl; e += 64)
       vx[e] = pH ? x_x[i * per + e] : 0.0;
     if (!last)
-      for (int e = lane; e < n; e += 64)
+      for (int e = lane + 64; e < n; e += 64)
         vd[e] = pCT ? x_y[s.y_dyn + (n + ck.cn) + e] : 0.0;
-    for (int k = lane; k < nrows; k += 64) {
+    for (int k = lane + 64; k < nrows; k += 64) {
       const bool iny = row_is_y(k);
       vr[k] = iny ? (pCT ? x_y[row_at(k)] : 0.0) : (pGT ? x_z[row_at(k)] : 0.0);
     }
-    stage_copy2(th, s.titem, theta_item_len(ck, ct, last), lane);
     const ThetaStage ts = theta_stage(ck, ct, th, last);
     // rows += J_theta theta
     if (pH) {
       for (int j = lane; j < xl; j += 64) {
         double *dst = y_x + i * per + j;
+        const double old = j == lane ? o_x : *dst;
         if (j < n) { // the node's block, then the edge's (the order of the node / edge loops of the reference)
           double an = 0.0, ae = 0.0;
           for (int a = 0; a < P; ++a)
@@ -565,12 +594,12 @@ apply_theta_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double
           if (!last)
             for (int a = 0; a < P; ++a)
               ae += ts.EX[j + n * a] * tv[a];
-          *dst = last ? *dst + an : (*dst + an) + ae;
+          *dst = last ? old + an : (old + an) + ae;
         } else {
           double au = 0.0;
           for (int a = 0; a < P; ++a)
             au += ts.EU[(j - n) + m * a] * tv[a];
-          *dst += au;
+          *dst = old + au;
         }
       }
     }
@@ -579,7 +608,8 @@ apply_theta_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double
         double acc = 0.0;
         for (int a = 0; a < P; ++a)
           acc += ts.ED[j + n * a] * tv[a];
-        y_y[s.y_dyn + (n + ck.cn) + j] += acc;
+        double *dst = y_y + s.y_dyn + (n + ck.cn) + j;
+        *dst = (j == lane ? o_d : *dst) + acc;
       }
     if (pC || pG)
       for (int k = lane; k < nrows; k += 64) {
@@ -589,7 +619,8 @@ apply_theta_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double
         double acc = 0.0;
         for (int a = 0; a < P; ++a)
           acc += ts.row(a, k) * tv[a];
-        (iny ? y_y : y_z)[row_at(k)] += acc;
+        double *dst = (iny ? y_y : y_z) + row_at(k);
+        *dst = (k == lane ? o_r : *dst) + acc;
       }
     // y_theta += J_theta^T x (H, CT, GT) + H_theta_theta theta (H)
     if (pH || pCT || pGT)
