@@ -125,8 +125,10 @@ size_t sip_kkt_vector_offset(const sip_kkt_plan *plan, int table, int index);
  * q_mod, r_mod, c_mod, dyn_r2, the 1/r2 and 1/(w+r3) weights), the LQR
  * output and the Riccati factor state (LQR::Workspace, lqr.hpp:109-135). */
 size_t sip_kkt_work_bytes(const sip_kkt_plan *plan);
-/* which Riccati path the plan runs, e.g. "chain:chain_factor_solve_qw16<...>"
- * or "tree:general" */
+/* which Riccati path and which kernel variants the plan runs, e.g.
+ * "chain:chain_factor_solve_qw16<...> + chain condensation (A|B in place, Q|R packed) [benchmark-family instantiation]"
+ * or "tree:general".  The string belongs to the plan; sip_kkt_plan_set_theta appends to it (" + fused theta passes"),
+ * so a pointer obtained before that call must be fetched again after it. */
 const char *sip_kkt_kernel_name(const sip_kkt_plan *plan);
 
 /* Replaces CallbackProvider::factor (helpers.cpp:242-370): checks and inverts
@@ -233,7 +235,12 @@ size_t sip_kkt_theta_offset(const sip_kkt_plan *plan, int block, int index);
 /* Bytes of the extra device scratch: J_theta, K^-1 J_theta
  * (Workspace::RegularizedLQRData::theta_jacobian / theta_solution,
  * types.hpp:174-175), the Schur factor, theta_rhs and the stagewise rhs /
- * solution (types.hpp:176-179), for the whole batch. */
+ * solution (types.hpp:176-179), for the whole batch.  Plans of uniform chains
+ * never assemble J_theta (they read its entries from the theta arena where
+ * they are needed, csrc/kkt_theta_chain_kernels.hpp) and keep per-stage
+ * partial sums of the Schur complement and of J_theta^T K^-1 b in its place:
+ * the size reported here says which.  d_theta_work carries K^-1 J_theta and
+ * the Schur factor from sip_kkt_factor_theta to sip_kkt_solve_theta. */
 size_t sip_kkt_theta_work_bytes(const sip_kkt_plan *plan);
 
 int sip_kkt_factor_theta(const sip_kkt_plan *plan, const double *d_model,
