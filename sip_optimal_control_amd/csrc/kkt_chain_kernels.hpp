@@ -301,10 +301,12 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
   const int n = ck.n, m = ck.m, nn = n * n, nm = n * m;
   const bool last = it.last;
   const int c = it.c, g = it.g, ce = it.ce, ge = it.ge;
-  const double *Jc = buf + nn, *Jg = Jc + c * n;
-  const double *eb = buf + it.node_len; // edge item
+  // MATS: `buf` is the whole stage image.  Otherwise (right-hand sides only) it holds the constraint Jacobians alone,
+  // node's then edge's, packed: a fifth of the LDS, three times the workgroups per CU
+  const double *Jc = MATS ? buf + nn : buf, *Jg = Jc + c * n;
+  const double *eb = buf + it.node_len; // edge item (MATS)
   const int o_m = nn, o_r = o_m + nm, o_a = o_r + m * m, o_b = o_a + nn, o_j = o_b + nm;
-  const double *Jxc = eb + o_j, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
+  const double *Jxc = MATS ? eb + o_j : buf + (c + g) * n, *Juc = Jxc + ce * n, *Jxg = Juc + ce * m, *Jug = Jxg + ge * n;
   // MATS: the stage block of mats is assembled in LDS (obuf) and leaves as one coalesced copy -- the tile
   // epilogue below scatters single scalars (lane l of a tile row writes column l: 96-byte strides), which as
   // global stores were one 8-byte L2 transaction per lane and element
@@ -507,7 +509,7 @@ condense_chain_kernel(const ChainKkt ck_in, const double *__restrict__ model_all
   const ChainKkt ck = family_dims<FN, FM>(ck_in);
   extern __shared__ double sm[];
   // wr: one block of lds_rows per right-hand-side column when there are several (MATS = false)
-  double *buf = sm, *wl = buf + ck.lds_item, *wr = wl + ck.lds_rows,
+  double *buf = sm, *wl = buf + (MATS ? ck.lds_item : ck.lds_tail), *wr = wl + ck.lds_rows,
          *r1s = wr + (long)(MATS || ncols < 1 ? 1 : ncols) * ck.lds_rows;
   double *obuf = r1s + ((ck.n + ck.m + 1) & ~1); // MATS: the stage block of mats before it leaves
   const long p = blockIdx.x / (ck.T + 1);
@@ -523,13 +525,13 @@ condense_chain_kernel(const ChainKkt ck_in, const double *__restrict__ model_all
   // whole stage (node item + edge item are adjacent in the model arena) -> LDS
   if (MATS) {
     stage_copy2(buf, it.item, it.node_len + it.edge_len, tid);
-  } else { // the Jacobian tails only, at their usual places in the image
+  } else { // the constraint Jacobians only, packed (node's, then edge's)
     const int n = ck.n, m = ck.m, nn = n * n;
     const int o_tail = it.node_len + 2 * nn + 2 * n * m + m * m;
     if (it.last)
-      stage_copy2(buf + nn, it.item + nn, (it.c + it.g) * n, tid);
+      stage_copy2(buf, it.item + nn, (it.c + it.g) * n, tid);
     else
-      stage_copy_pair(buf + nn, it.item + nn, (it.c + it.g) * n, buf + o_tail, it.item + o_tail,
+      stage_copy_pair(buf, it.item + nn, (it.c + it.g) * n, buf + (it.c + it.g) * n, it.item + o_tail,
                       (it.ce + it.ge) * (n + m), tid);
   }
   condense_commit<WITH_RHS, MATS>(ck, it, tid, pre, wl, wr, r1s);

@@ -247,7 +247,9 @@ hipError_t launch_rhs(const sip_kkt_plan *p, const Regions &r, const double *mod
   if (p->chain_kernels)
     family_dispatch(p->family, [&](auto fn, auto fm) {
       hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false, decltype(fn)::value, decltype(fm)::value>),
-                         dim3(node_grid(p)), dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, p->ck, model,
+                         dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
+                         // (rhs only: the constraint Jacobians | weights | weighted rows)
+                         sizeof(double) * ((size_t)p->ck.lds_tail + 2 * (size_t)p->ck.lds_rows), s, p->ck, model,
                          (const double *)nullptr, r.inv, r.in0, b, r.in1, (long)p->batch, status);
     });
   else if (p->staged)
@@ -1008,13 +1010,14 @@ int sip_kkt_factor_theta(const sip_kkt_plan *p, const double *d_model, const dou
     const long colJ = (long)p->batch * skkt, colV = (long)p->batch * p->in1_len;
     // (LDS: one block of weighted rows per column; as many columns per launch as 64 KiB hold)
     const size_t rhs_col_lds = sizeof(double) * (size_t)p->ck.lds_rows;
-    const int rhs_cols = 1 + (int)std::min<size_t>((size_t)(th - 1), (64 * 1024 - p->lds_chain_condense) / std::max<size_t>(rhs_col_lds, 1));
+    const size_t rhs_lds = sizeof(double) * ((size_t)p->ck.lds_tail + 2 * (size_t)p->ck.lds_rows); // one column
+    const int rhs_cols = 1 + (int)std::min<size_t>((size_t)(th - 1), (64 * 1024 - rhs_lds) / std::max<size_t>(rhs_col_lds, 1));
     for (int c0 = 0; c0 < th; c0 += rhs_cols) {
       const int nc = std::min(rhs_cols, th - c0);
       family_dispatch(p->family, [&](auto fn, auto fm) {
         hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, false, decltype(fn)::value, decltype(fm)::value>),
                            dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                           p->lds_chain_condense + rhs_col_lds * (size_t)(nc - 1), s, p->ck, d_model,
+                           rhs_lds + rhs_col_lds * (size_t)(nc - 1), s, p->ck, d_model,
                            (const double *)nullptr, r.inv, r.in0, (const double *)t.J + (size_t)c0 * colJ,
                            t.vecs_cols + (size_t)c0 * colV, (long)p->batch, (const int32_t *)d_status, nc, colJ, colV);
       });
