@@ -204,24 +204,29 @@ hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double
   const bool pipe = p->chain_kernels && p->chain_pipe > 0 && ((uintptr_t)model & 15) == 0;
   const unsigned pipe_grid =
       pipe ? (unsigned)(((long)p->batch * p->N + p->chain_pipe - 1) / p->chain_pipe) : 0u;
+  // LDS of the chain kernels: image | weights | weighted rows | r1 slice | the outgoing block of mats -- of THIS
+  // layout (split / packed blocks are smaller: more workgroups per CU)
+  const size_t lds_chain = p->chain_kernels ? sizeof(double) * ((size_t)ck.lds_item + 2 * (size_t)ck.lds_rows +
+                                                                 (size_t)even(ck.n + ck.m) + (size_t)ck.mats_stage)
+                                            : 0;
   if (pipe && b != nullptr)
     family_dispatch(p->family, [&](auto fn, auto fm) {
       hipLaunchKernelGGL((sipamd::kkt::condense_chain_pipe_kernel<true, decltype(fn)::value, decltype(fm)::value>),
-                         dim3(pipe_grid), dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, b,
+                         dim3(pipe_grid), dim3(sipamd::kkt::TPB), lds_chain, s, ck, model, r1, r.inv, r.in0, b,
                          r.in1, (long)p->batch, p->chain_pipe);
     });
   else if (pipe)
     family_dispatch(p->family, [&](auto fn, auto fm) {
       hipLaunchKernelGGL((sipamd::kkt::condense_chain_pipe_kernel<false, decltype(fn)::value, decltype(fm)::value>),
-                         dim3(pipe_grid), dim3(sipamd::kkt::TPB), p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0,
+                         dim3(pipe_grid), dim3(sipamd::kkt::TPB), lds_chain, s, ck, model, r1, r.inv, r.in0,
                          (const double *)nullptr, (double *)nullptr, (long)p->batch, p->chain_pipe);
     });
   else if (p->chain_kernels && b != nullptr)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
+                       lds_chain, s, ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
   else if (p->chain_kernels)
     hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       p->lds_chain_condense, s, ck, model, r1, r.inv, r.in0, (const double *)nullptr,
+                       lds_chain, s, ck, model, r1, r.inv, r.in0, (const double *)nullptr,
                        (double *)nullptr, (long)p->batch);
   else if (p->staged && b != nullptr) // condensation and right-hand side from one staging of the model
     hipLaunchKernelGGL(sipamd::kkt::condense_staged_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
