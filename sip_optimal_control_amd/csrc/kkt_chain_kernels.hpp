@@ -495,8 +495,13 @@ __device__ __forceinline__ void condense_compute(const ChainKkt &ck, const Conde
 // WITH_RHS: also q_mod / r_mod / c_mod from b.  MATS = false (the split solve path): ONLY those --
 // the Jacobians of the stage are staged, no Q_mod / M_mod / R_mod / A / B work, `status` problems
 // with a failed factorization are skipped.
+// (the same for the rhs-only condensation of sip_kkt_solve: 8 wavefronts per SIMD, solve 0.63 -> 0.557 ms; the K x
+// kernel loses with any cap -- 0.48 -> 0.49 / 0.72 ms at 6 / 8 -- and keeps its 96 registers)
+#ifndef SIP_KKT_RHS_WAVES
+#define SIP_KKT_RHS_WAVES 8
+#endif
 template <bool WITH_RHS, bool MATS = true, int FN = 0, int FM = 0>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FN > 0 && !MATS ? SIP_KKT_RHS_WAVES : 1, 8)))
 condense_chain_kernel(const ChainKkt ck_in, const double *__restrict__ model_all, const double *__restrict__ r1_all,
                       const double *__restrict__ inv_all, double *__restrict__ mats_all,
                       const double *__restrict__ b_all, double *__restrict__ vecs_all, long batch,
@@ -562,8 +567,13 @@ __device__ unsigned long long g_kkt_seg[16];
   } while (0)
 #endif
 constexpr int PIPE_U = 8;
+// (no cap: held to 5 wavefronts per SIMD -- 96 registers -- the family instantiation of the pipelined condensation
+// makes the step 0.85 ms against 0.77)
+#ifndef SIP_KKT_PIPE_WAVES
+#define SIP_KKT_PIPE_WAVES 1
+#endif
 template <bool WITH_RHS, int FN = 0, int FM = 0>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FN > 0 ? SIP_KKT_PIPE_WAVES : 1, 8)))
 condense_chain_pipe_kernel(const ChainKkt ck_in, const double *__restrict__ model_all,
                            const double *__restrict__ r1_all, const double *__restrict__ inv_all,
                            double *__restrict__ mats_all, const double *__restrict__ b_all,
@@ -648,8 +658,14 @@ condense_chain_pipe_kernel(const ChainKkt ck_in, const double *__restrict__ mode
 // x, u, y scatter + multipliers of node i and edge i (helpers.cpp:817-892).  COLS: the instantiation
 // for several columns per launch (the two-phase form below) -- a kernel of its own so that the
 // single-column one keeps its 58 registers and eight wavefronts per SIMD.
+// Wavefronts per SIMD the register allocator is held to in the benchmark-family instantiation of the single-column
+// recovery: unrolled over the compile-time dimensions it took 122 registers (4 wavefronts per SIMD) where the generic one
+// takes 58 (8); held to 64 registers the Newton-KKT step runs 0.768 against 0.792 ms (6 wavefronts: 0.787).
+#ifndef SIP_KKT_RECOVER_WAVES
+#define SIP_KKT_RECOVER_WAVES 8
+#endif
 template <bool COLS = false, int FN = 0, int FM = 0>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FN > 0 && !COLS ? SIP_KKT_RECOVER_WAVES : 1, 8)))
 recover_chain_kernel(const ChainKkt ck_in, const double *__restrict__ model_all, const double *__restrict__ b_all,
                      const double *__restrict__ inv_all, const double *__restrict__ lqr_sol_all,
                      double *__restrict__ sol_all, const int32_t *__restrict__ status, long batch,
@@ -825,8 +841,11 @@ recover_chain_kernel(const ChainKkt ck_in, const double *__restrict__ model_all,
 // rows of stage i, the dynamics rows of node i + 1 (plus the root's at i = 0) and the constraint
 // rows of node i and edge i: everything they touch is in stage i's model item (staged in LDS) and
 // in a few slices of x.  x-space vectors are [x | theta (th entries)].
+#ifndef SIP_KKT_APPLY_WAVES
+#define SIP_KKT_APPLY_WAVES 1
+#endif
 template <int FN = 0, int FM = 0>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FN > 0 ? SIP_KKT_APPLY_WAVES : 1, 8)))
 apply_chain_kernel(const ChainKkt ck_in, const int th, const double *__restrict__ model_all,
                    const double *__restrict__ w_all, const double *__restrict__ r1_all,
                    const double *__restrict__ r2_all, const double *__restrict__ r3_all, const ApplyIO io,

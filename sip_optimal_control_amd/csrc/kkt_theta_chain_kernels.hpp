@@ -27,6 +27,12 @@
 #include "kkt_chain_kernels.hpp"
 #include "kkt_theta_kernels.hpp"
 
+// wavefronts per SIMD the rhs / recover stage kernels are held to in the family instantiation (1: no cap; held to 8 --
+// 64 registers -- `factor_theta` takes 2.67 ms against 2.54)
+#ifndef SIP_KKT_THETA_WAVES
+#define SIP_KKT_THETA_WAVES 1
+#endif
+
 namespace sipamd {
 namespace kkt {
 
@@ -208,7 +214,7 @@ __device__ __forceinline__ long theta_row_at(const ChainKkt &ck, const ThetaStag
 // order as condense_chain_kernel<rhs only> forms them from an assembled J_theta.
 // LDS: [Jacobian tails (lds_tail) | theta item (ct.lds_item) | weights (lds_rows) | weighted rows, p x lds_rows]
 template <int FN = 0, int FM = 0>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FN > 0 ? SIP_KKT_THETA_WAVES : 1, 8)))
 theta_rhs_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double *__restrict__ model_all,
                        const double *__restrict__ theta_all, const double *__restrict__ inv_all,
                        double *__restrict__ vecs_cols, const long vecs_col_stride,
@@ -276,7 +282,7 @@ theta_rhs_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double *
 // LDS: [Jacobian tails (lds_tail) | theta item | x_i|u_i of the columns, p (n + m) | y_{i+1} of the columns, p n |
 //       multipliers of the columns, p x lds_rows | weights, lds_rows]
 template <int FN = 0, int FM = 0>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FN > 0 ? SIP_KKT_THETA_WAVES : 1, 8)))
 theta_recover_chain_kernel(const ChainKkt ck_in, const ChainTheta ct, const double *__restrict__ model_all,
                            const double *__restrict__ theta_all, const double *__restrict__ inv_all,
                            const double *__restrict__ lqr_sol_cols, const long lqr_col_stride,
