@@ -3,7 +3,7 @@
 # per-kernel means printed by tools/pmc_table.py.  usage: tools/pmc_kkt.sh <tag> [bench_kkt args]
 set -o pipefail
 TAG=${1:-kkt_pmc}; shift
-OUT=gpurun_out/prof/$TAG
+OUT=${PMC_OUT:-gpurun_out/prof}/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 5 --cpu-seconds 0 $@"

@@ -15,7 +15,7 @@ for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=Tru
         names[(path, row["Dispatch_Id"])] = row["Kernel_Name"]
     for (pth, disp, ctr), val in per_dispatch.items():
         acc[names[(pth, disp)]][ctr].append(val)
-want = sys.argv[2:] or ["chain_kernel", "qw16", "mf32", "staged_kernel", "theta"]
+want = sys.argv[2:] or ["chain_kernel", "pipe_kernel", "weights_kernel", "qw16", "mf32", "mt16", "staged_kernel", "theta"]
 for kern, ctrs in acc.items():
     if not any(w in kern for w in want):
         continue
