@@ -184,7 +184,9 @@ int sip_lqr_factor_solve(const sip_lqr_plan *plan, const void *d_mats,
  *           chain layout, edge blocks [M | R] (no A, B);
  *   d_ab  : stage i of problem p: A (n x n, column-major) then B (n x m, column-major) at
  *           d_ab + (p * ab_problem_stride + i * ab_stage_stride) scalars.
- * 16-byte aligned bases and strides; 3 * ab_problem_stride * 8 + (n*n + n*m) * 8 < 2^32 bytes (the four
+ * d_mats, d_vecs, d_gains, d_workspace 16-byte aligned; d_ab and its strides any (8-byte aligned scalars: a stage's
+ * A | B is a whole number of 16-byte pieces and is copied exactly from sources that are only 8-byte aligned);
+ * 3 * ab_problem_stride * 8 + (n*n + n*m) * 8 < 2^32 bytes (the four
  * problems of a wavefront are addressed by 32-bit offsets; SIP_LQR_ERR_INVALID_ARGUMENT beyond: that is
  * a problem stride of up to ~178 M scalars).  Available (sip_lqr_has_split() == 1) for fp64 plans whose fused
  * kernel is an LDS-staged one (n <= 15, m <= 8) and whose A | B block is a whole number of 16-byte pieces

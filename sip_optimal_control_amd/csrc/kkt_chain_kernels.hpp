@@ -600,11 +600,17 @@ condense_chain_pipe_kernel(const ChainKkt ck_in, const double *__restrict__ mode
   };
   // split: the pieces of ddyn_dx | ddyn_du are not fetched (nothing here reads them; the Riccati
   // sweep takes them from the arena itself) -- their lanes re-read the piece in front of them
-  const int ab_first = ck.split ? (ck.node_len + ck.n * ck.n + ck.n * ck.m + ck.m * ck.m) >> 1 : 0;
-  const int ab_end = ck.split ? ab_first + ((ck.n * ck.n + ck.n * ck.m) >> 1) : 0;
+  // (whole pieces inside the block only: with odd m it starts on an odd scalar, and the piece across its first
+  // boundary carries the last entry of R)
+  const int ab_at = ck.node_len + ck.n * ck.n + ck.n * ck.m + ck.m * ck.m;
+  const int ab_first = ck.split ? (ab_at + 1) >> 1 : 0;
+  const int ab_end = ck.split ? (ab_at + ck.n * ck.n + ck.n * ck.m) >> 1 : 0;
   auto image_load = [&](const CondenseItem &it, d2_t (&v)[PIPE_U]) {
-    const d2_t *s2 = (const d2_t *)it.item;
-    const int len2 = (it.node_len + it.edge_len) >> 1;
+    // (an item of odd length, or an arena at an odd scalar: 16-byte pieces from 8-byte aligned addresses; the last
+    // piece of an odd item ends with the first scalar of the item behind it)
+    typedef d2_t d2u_t __attribute__((aligned(8)));
+    const d2u_t *s2 = (const d2u_t *)it.item;
+    const int len2 = (it.node_len + it.edge_len + 1) >> 1;
 #pragma unroll
     for (int u = 0; u < PIPE_U; ++u) {
       int q = min(tid + u * TPB, len2 - 1);
@@ -625,7 +631,7 @@ condense_chain_pipe_kernel(const ChainKkt ck_in, const double *__restrict__ mode
   for (long idx = first; idx < end; ++idx) {
     { // registers -> LDS
       d2_t *d2 = (d2_t *)buf;
-      const int len2 = (cur.node_len + cur.edge_len) >> 1;
+      const int len2 = (cur.node_len + cur.edge_len + 1) >> 1;
 #pragma unroll
       for (int u = 0; u < PIPE_U; ++u) // (lanes past the end hold a copy of the last piece: the same store)
         d2[min(tid + u * TPB, len2 - 1)] = img[u];

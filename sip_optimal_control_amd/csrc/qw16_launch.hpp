@@ -85,11 +85,12 @@ hipError_t launch_qw16_split(long batch, int T, const void *mats, const void *ab
                              const void *vecs, void *sol, void *gains, int32_t *status, void *ws,
                              hipStream_t stream) {
   using Cfg = StagedCfg<N, M, true, true, SYM>;
-  // 16-byte pieces: bases and strides (the LDS-DMA itself is exact from 8-byte-aligned sources on
-  // gfx950, tools/ubench/lds_dma_align.hip, but the per-problem / per-stage strides must keep the pieces whole)
-  const uintptr_t bits = (uintptr_t)mats | (uintptr_t)vecs | (uintptr_t)gains | (uintptr_t)ws | (uintptr_t)ab |
-                         (uintptr_t)(ab_pstride * 8) | (uintptr_t)(ab_sstride * 8);
-  if (bits & 15)
+  // 16-byte aligned arrays of this library's own layouts; A | B -- the caller's -- at any 8-byte aligned place and
+  // strides: a stage's A | B is a whole number of 16-byte pieces (AB even, StagedCfg) and the LDS-DMA of gfx950 copies
+  // pieces exactly from sources that are only 8-byte aligned (tools/ubench/lds_dma_align.hip), as the odd-length
+  // stage blocks of `mats` already rely on
+  const uintptr_t bits = (uintptr_t)mats | (uintptr_t)vecs | (uintptr_t)gains | (uintptr_t)ws;
+  if ((bits & 15) || ((uintptr_t)ab & 7))
     return hipErrorInvalidValue;
   hipLaunchKernelGGL((chain_factor_solve_qw16<N, M, true, true, true, SYM>), dim3((unsigned)((batch + 3) / 4)), dim3(64),
                      Cfg::LDS_BYTES, stream, (const double *)mats, (const double *)vecs, (double *)sol,

@@ -201,33 +201,55 @@ hipError_t launch_condense(const sip_kkt_plan *p, const Regions &r, const double
     hipLaunchKernelGGL(sipamd::kkt::weights_kernel, dim3((unsigned)((p->batch * per + 255) / 256)), dim3(256), 0, s,
                        p->meta, w, r2, r3, r.inv, r.reg, (long)p->batch);
   // the pipelined kernel copies 16-byte pieces: the arena itself has to be 16-byte aligned
-  const bool pipe = p->chain_kernels && p->chain_pipe > 0 && ((uintptr_t)model & 15) == 0;
-  const unsigned pipe_grid =
-      pipe ? (unsigned)(((long)p->batch * p->N + p->chain_pipe - 1) / p->chain_pipe) : 0u;
+  const bool pipe = p->chain_kernels && p->chain_pipe > 0 && ((uintptr_t)model & 7) == 0;
+  // the last item of the arena, if of odd length: its last 16-byte piece would reach 8 bytes past the caller's array
+  const bool odd_tail = pipe && ((ck.n * ck.n + (ck.cT + ck.gT) * ck.n) & 1);
+  const long pipe_batch = odd_tail ? (long)p->batch - 1 : (long)p->batch;
+  const unsigned pipe_grid = pipe ? (unsigned)((pipe_batch * p->N + p->chain_pipe - 1) / p->chain_pipe) : 0u;
   // LDS of the chain kernels: image | weights | weighted rows | r1 slice | the outgoing block of mats -- of THIS
   // layout (split / packed blocks are smaller: more workgroups per CU)
   const size_t lds_chain = p->chain_kernels ? sizeof(double) * ((size_t)ck.lds_item + 2 * (size_t)ck.lds_rows +
                                                                  (size_t)even(ck.n + ck.m) + (size_t)ck.mats_stage)
                                             : 0;
-  if (pipe && b != nullptr)
-    family_dispatch(p->family, [&](auto fn, auto fm) {
-      hipLaunchKernelGGL((sipamd::kkt::condense_chain_pipe_kernel<true, decltype(fn)::value, decltype(fm)::value>),
-                         dim3(pipe_grid), dim3(sipamd::kkt::TPB), lds_chain, s, ck, model, r1, r.inv, r.in0, b,
-                         r.in1, (long)p->batch, p->chain_pipe);
-    });
-  else if (pipe)
-    family_dispatch(p->family, [&](auto fn, auto fm) {
-      hipLaunchKernelGGL((sipamd::kkt::condense_chain_pipe_kernel<false, decltype(fn)::value, decltype(fm)::value>),
-                         dim3(pipe_grid), dim3(sipamd::kkt::TPB), lds_chain, s, ck, model, r1, r.inv, r.in0,
-                         (const double *)nullptr, (double *)nullptr, (long)p->batch, p->chain_pipe);
-    });
-  else if (p->chain_kernels && b != nullptr)
-    hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       lds_chain, s, ck, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
-  else if (p->chain_kernels)
-    hipLaunchKernelGGL(sipamd::kkt::condense_chain_kernel<false>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
-                       lds_chain, s, ck, model, r1, r.inv, r.in0, (const double *)nullptr,
-                       (double *)nullptr, (long)p->batch);
+  // one-stage kernel over `nb` problems starting at problem `q0`
+  auto one_stage = [&](const long q0, const long nb) {
+    const long kkt_len = (long)p->x_dim + p->y_dim + p->z_dim;
+    const double *mq = model + q0 * ck.model_len, *r1q = r1 + q0 * p->x_dim, *invq = r.inv + q0 * ((long)p->y_dim + p->z_dim);
+    double *in0q = r.in0 + q0 * ck.mats_len;
+    if (b != nullptr) {
+      const double *bq = b + q0 * kkt_len;
+      double *in1q = r.in1 + q0 * ck.vecs_len;
+      family_dispatch(p->family, [&](auto fn, auto fm) {
+        hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<true, true, decltype(fn)::value, decltype(fm)::value>),
+                           dim3((unsigned)(nb * p->N)), dim3(sipamd::kkt::TPB), lds_chain, s, ck, mq, r1q, invq, in0q, bq,
+                           in1q, nb);
+      });
+    } else {
+      family_dispatch(p->family, [&](auto fn, auto fm) {
+        hipLaunchKernelGGL((sipamd::kkt::condense_chain_kernel<false, true, decltype(fn)::value, decltype(fm)::value>),
+                           dim3((unsigned)(nb * p->N)), dim3(sipamd::kkt::TPB), lds_chain, s, ck, mq, r1q, invq, in0q,
+                           (const double *)nullptr, (double *)nullptr, nb);
+      });
+    }
+  };
+  if (pipe) {
+    if (pipe_batch > 0 && b != nullptr)
+      family_dispatch(p->family, [&](auto fn, auto fm) {
+        hipLaunchKernelGGL((sipamd::kkt::condense_chain_pipe_kernel<true, decltype(fn)::value, decltype(fm)::value>),
+                           dim3(pipe_grid), dim3(sipamd::kkt::TPB), lds_chain, s, ck, model, r1, r.inv, r.in0, b,
+                           r.in1, pipe_batch, p->chain_pipe);
+      });
+    else if (pipe_batch > 0)
+      family_dispatch(p->family, [&](auto fn, auto fm) {
+        hipLaunchKernelGGL((sipamd::kkt::condense_chain_pipe_kernel<false, decltype(fn)::value, decltype(fm)::value>),
+                           dim3(pipe_grid), dim3(sipamd::kkt::TPB), lds_chain, s, ck, model, r1, r.inv, r.in0,
+                           (const double *)nullptr, (double *)nullptr, pipe_batch, p->chain_pipe);
+      });
+    if (odd_tail)
+      one_stage((long)p->batch - 1, 1);
+  } else if (p->chain_kernels) { // (SIP_KKT_PIPE=0, or an item longer than one pass of the pipelined walk)
+    one_stage(0, (long)p->batch);
+  }
   else if (p->staged && b != nullptr) // condensation and right-hand side from one staging of the model
     hipLaunchKernelGGL(sipamd::kkt::condense_staged_kernel<true>, dim3(node_grid(p)), dim3(sipamd::kkt::TPB),
                        p->lds_condense, s, p->meta, model, r1, r.inv, r.in0, b, r.in1, (long)p->batch);
@@ -561,9 +583,11 @@ int sip_kkt_plan_create(int64_t batch, int num_edges, int root, const int *edge_
     const int len_mid = ck.node_len + ck.edge_len, len_last = n * n + (ck.cT + ck.gT) * n;
     const char *pe = std::getenv("SIP_KKT_PIPE");
     const int per = pe ? std::atoi(pe) : 6;
-    const bool fits = len_mid % 2 == 0 && len_last % 2 == 0 && ck.model_len % 2 == 0 &&
-                      len_mid / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB &&
-                      len_last / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB;
+    // (any lengths: an image of odd length takes one more piece, whose second half is the first scalar of the item
+    // behind it; sources are then only 8-byte aligned, which the vector loads take.  The batch's very last item has
+    // nothing behind it: launch_condense gives the last problem to the one-stage kernel when that matters.)
+    const bool fits = (len_mid + 1) / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB &&
+                      (len_last + 1) / 2 <= sipamd::kkt::PIPE_U * sipamd::kkt::TPB;
     p->chain_pipe = fits && per > 0 ? per : 0;
     {
       const int fn = ck.n, fm = ck.m, fc = std::max(1, fn / 2), fg = std::max(1, 2 * fm);
@@ -759,12 +783,11 @@ int sip_kkt_factor_solve(const sip_kkt_plan *p, const double *d_model, const dou
   hipStream_t s = (hipStream_t)stream;
   const Regions r = regions(p, d_work);
   const bool fused_rhs = p->staged || p->chain_kernels;
-  // The dynamics Jacobians stay where the model callback left them when the sweep can read them
-  // in place (16-byte pieces: aligned arena, even block offsets and strides).
+  // The dynamics Jacobians stay where the model callback left them: the sweep reads them in place, at whatever
+  // 8-byte aligned offsets and strides the arena puts them (odd m: odd ones; launch_qw16_split)
   const long ab_off = (long)p->ck.node_len + p->ck.n * p->ck.n + p->ck.n * p->ck.m + p->ck.m * p->ck.m;
   const long ab_stage = (long)p->ck.node_len + p->ck.edge_len;
-  const bool split = p->chain_split && fused_rhs && p->E > 0 &&
-                     ((((uintptr_t)d_model >> 3) | (uintptr_t)ab_off | (uintptr_t)ab_stage | (uintptr_t)p->ck.model_len) & 1) == 0;
+  const bool split = p->chain_split && fused_rhs && p->E > 0 && ((uintptr_t)d_model & 7) == 0;
   const bool sym = split && p->chain_sym != nullptr;
   hipError_t e = launch_condense(p, r, d_model, d_w, d_r1, d_r2, d_r3, fused_rhs ? d_b : nullptr, s, split, sym);
   if (e == hipSuccess && !fused_rhs)

@@ -85,6 +85,32 @@ def test_split_reads_strided_jacobians():
     assert torch.equal(sol, sol2) and torch.equal(gains, gains2)
 
 
+@pytest.mark.parametrize("n,m", [(12, 3), (12, 4), (5, 3), (8, 1)])
+def test_split_reads_jacobians_at_odd_offsets_and_strides(n, m):
+    """A | B at places that are only 8-byte aligned -- an odd offset inside a record of odd length inside a problem
+    arena of odd length, as the Newton-KKT model arena has them for odd m: a stage's A | B is a whole number of
+    16-byte pieces, and the LDS-DMA copies pieces exactly from 8-byte aligned sources (tools/ubench/lds_dma_align.hip).
+    Bitwise the packed sweep."""
+    T, batch = 9, 11
+    solver, mats, vecs = _problem(n, m, T, batch, seed=5 * n + m)
+    if not solver.has_split:
+        pytest.skip("no split kernel")
+    qmr, ab = solver.split_inputs(mats)
+    rec, off = 2 * n * (n + m) + 7, 3  # odd record length, odd offset
+    per = (T + 2) * rec + (1 - ((T + 2) * rec) % 2)  # odd problem stride
+    flat = torch.full((batch * per + 2,), float("nan"), dtype=torch.float64, device="cuda:0")
+    base = 1 if (flat.data_ptr() // 8) % 2 == 0 else 2  # ... from a base whose A | B lands on an odd scalar
+    arena = flat[base:base + batch * per].view(batch, per)[:, :(T + 2) * rec].unflatten(1, (T + 2, rec))
+    view = arena[:, 1:T + 1, off:off + n * (n + m)]
+    assert view.stride(0) % 2 == 1 and view.stride(1) % 2 == 1 and view.data_ptr() % 16 == 8
+    view.copy_(ab)
+    sol, gains, status = (t.clone() for t in solver.factor_solve(mats, vecs))
+    sol2, gains2, status2 = solver.factor_solve_split(qmr, view, vecs)
+    torch.cuda.synchronize()
+    assert int(status2.abs().sum()) == 0
+    assert torch.equal(sol, sol2) and torch.equal(gains, gains2)
+
+
 def test_split_statuses():
     """Factorization failures are reported as by the packed kernel (lqr.hpp:68-74)."""
     n, m, T, batch = 12, 4, 20, 16

@@ -217,7 +217,7 @@ def test_packed_condensation_gives_the_same_bits(monkeypatch, n, m, T):
     assert float(np.abs(sol_p.cpu().numpy() - ref).max() / np.abs(ref).max()) <= 1e-9
 
 
-@pytest.mark.parametrize("n,m", [(10, 5), (14, 2), (7, 7), (15, 1), (2, 8)])
+@pytest.mark.parametrize("n,m", [(10, 5), (14, 2), (7, 7), (15, 1), (2, 8), (12, 3), (8, 1), (4, 3), (6, 1)])
 def test_in_place_jacobians_outside_the_benchmark_grid(monkeypatch, n, m):
     """the step reads ddyn_dx | ddyn_du in place for every staged shape whose A | B block is a whole
     number of 16-byte pieces, not only the benchmark grid -- the same bits as the copying step."""

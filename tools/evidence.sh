@@ -15,6 +15,7 @@ for w in c3 c2 c4 kkt; do
 done
 timeout -k 10 200 python tests/bench_kkt.py --theta 8 --steps 10 2>/dev/null | tail -1 > $OUT/bench_theta8.json
 timeout -k 10 200 python tools/bench_tree.py 2>/dev/null | tail -1 > $OUT/bench_tree.json
+timeout -k 10 300 python tools/kkt_grid_times.py > $OUT/kkt_grid.md 2>/dev/null
 timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c3 > $OUT/prof_c3.log 2>&1
 timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c4 --workload c4 > $OUT/prof_c4.log 2>&1
 timeout -k 10 300 tools/profile_gpu.sh ${TAG}_c2 --workload c2 > $OUT/prof_c2.log 2>&1

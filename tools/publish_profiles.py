@@ -85,6 +85,17 @@ def main():
                 f"frac {kkt['roofline']['frac']:.3f}** (`profiles/{tag}_bench_kkt.json`).\n"
                 "History of the three big launches (condensation / sweep / recovery): round 2 474 / 328 / 193 us; round 3 with the\n"
                 "generic instantiations 472 / 327 / 195 us; with the compile-time benchmark-family instantiations the figures above.\n")
+    grid = os.path.join(out, "kkt_grid.md")
+    if os.path.exists(grid):
+        with open(os.path.join(prof_out, f"{tag}_kkt", "grid.md"), "w") as f:
+            f.write("# Newton-KKT factor + solve over the reference's benchmark grid -- `tools/kkt_grid_times.py`\n\n"
+                    "NewtonKKTProblem(n, m, T = 50) with c = n / 2 and g = 2 m rows per edge and on the last node "
+                    "(newton_kkt_benchmark.cpp:59-80, 264-273), batch 4096, fp64, HIP events over 20 steps after 3.\n"
+                    "Odd m: the stage items and the places of `A | B` in the model arena are odd numbers of scalars -- the pipelined "
+                    "condensation and the in-place sweep take them from 8-byte aligned addresses (round 3; before, those shapes "
+                    "ran the one-stage generic condensation and copied `A | B`: (12, 3) 1.09 ms, (12, 1) 0.92, (8, 3) 0.78, (8, 1) 0.70, "
+                    "(4, 3) 0.63, (4, 1) 0.55 ms).\n\n")
+            f.write(open(grid).read())
     traffic_path = os.path.join(prof_out, "traffic.json")
     t = json.load(open(traffic_path))
     t[f"kkt:{kkt['config']['kernels']}"] = {
